@@ -1,0 +1,146 @@
+"""Loader for the CPU oracle (oracle/libsf_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from strikeforce_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "libsf_oracle.so")
+        src = os.path.join(ROOT, "oracle", "sf_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libsf_oracle.so"])
+        L = C.CDLL(path)
+        L.sfo_create.argtypes = [C.POINTER(abi.Config)]
+        L.sfo_create.restype = C.c_void_p
+        abi.bind(L, "sfo_")
+        L.sfo_step_many.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        L.sfo_kat_rand.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_int32)]
+        L.sfo_kat_compute_damage.argtypes = [C.c_int32, C.c_int32]
+        L.sfo_kat_compute_damage.restype = C.c_int32
+        L.sfo_draws.argtypes = [C.c_void_p, C.c_int32]
+        L.sfo_draws.restype = C.c_int64
+        L.sfo_bench_run.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]
+        L.sfo_bench_run.restype = C.c_int64
+        _LIB = L
+    return _LIB
+
+
+class ArenaDump:
+    def __init__(self, hdr, humans, zombies, bullets, portals, flags, dmg, pidx):
+        self.hdr, self.humans, self.zombies, self.bullets, self.portals = hdr, humans, zombies, bullets, portals
+        self.flags, self.dmg, self.pidx = flags, dmg, pidx
+
+    def as_dict(self):
+        return {
+            "hdr": abi.struct_to_dict(self.hdr),
+            "humans": [abi.struct_to_dict(h) for h in self.humans],
+            "zombies": [abi.struct_to_dict(z) for z in self.zombies],
+            "bullets": [abi.struct_to_dict(b) for b in self.bullets],
+            "portals": [abi.struct_to_dict(p) for p in self.portals],
+            "flags": self.flags.tolist(), "dmg": self.dmg.tolist(), "pidx": self.pidx.tolist(),
+        }
+
+
+def dump_with(fn, handle, cfg, arena):
+    """Call a *_dump_arena entry point and return an ArenaDump."""
+    cells = cfg.floors * cfg.rows * cfg.cols
+    hdr = abi.ArenaHdr()
+    hs = (abi.HumanRec * cfg.cap_humans)()
+    zs = (abi.ZombieRec * cfg.cap_zombies)()
+    bs = (abi.BulletRec * cfg.cap_bullets)()
+    ps = (abi.PortalRec * cfg.cap_portals)()
+    flags = np.zeros(cells, dtype=np.uint8)
+    dmg = np.zeros(cells, dtype=np.int32)
+    pidx = np.zeros(cells, dtype=np.int32)
+    rc = fn(handle, arena, C.byref(hdr), hs, zs, bs, ps, flags.ctypes.data_as(C.POINTER(C.c_uint8)),
+            dmg.ctypes.data_as(C.POINTER(C.c_int32)), pidx.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert rc == 0, rc
+    return ArenaDump(hdr, list(hs), list(zs), list(bs), list(ps), flags, dmg, pidx)
+
+
+def diff_dumps(a, b, path=""):
+    """First difference between two as_dict() dumps, as a readable string (None if identical)."""
+    if isinstance(a, dict):
+        for k in a:
+            d = diff_dumps(a[k], b[k], path + "/" + str(k))
+            if d:
+                return d
+        return None
+    if isinstance(a, list):
+        if len(a) != len(b):
+            return "%s: len %d != %d" % (path, len(a), len(b))
+        for i, (x, y) in enumerate(zip(a, b)):
+            d = diff_dumps(x, y, path + "[%d]" % i)
+            if d:
+                return d
+        return None
+    return None if a == b else "%s: %r != %r" % (path, a, b)
+
+
+class Oracle:
+    """The reference algorithm on the CPU, same call surface as strikeforce_amd.env.ArenaBatch."""
+
+    def __init__(self, workload):
+        self.w = workload
+        self.cfg = workload.cfg
+        self.L = lib()
+        self.h = self.L.sfo_create(C.byref(self.cfg))
+        if not self.h:
+            raise ValueError("oracle rejected the configuration")
+
+    def close(self):
+        if self.h:
+            self.L.sfo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def reset(self, tb, serial):
+        self.L.sfo_reset(self.h, tb, serial)
+
+    def step(self, cmd):
+        cmd = np.ascontiguousarray(cmd, dtype=np.uint8)
+        assert cmd.size == self.cfg.arenas * self.cfg.n_agents
+        self.L.sfo_step(self.h, cmd.ctypes.data_as(C.c_char_p))
+
+    def step_many(self, cmds):
+        cmds = np.ascontiguousarray(cmds, dtype=np.uint8)
+        k = cmds.shape[0]
+        self.L.sfo_step_many(self.h, cmds.ctypes.data_as(C.c_char_p), k)
+
+    def observe(self):
+        out = np.empty((self.cfg.arenas, self.cfg.n_agents, abi.OBS_CHANNELS, abi.OBS_WINDOW, abi.OBS_WINDOW),
+                       dtype=np.float32)
+        self.L.sfo_observe(self.h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def results(self):
+        out = np.zeros((self.cfg.arenas, self.cfg.n_agents, 8), dtype=np.int32)
+        self.L.sfo_results(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)))
+        return out
+
+    def done(self):
+        out = np.zeros(self.cfg.arenas, dtype=np.uint8)
+        self.L.sfo_done(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out
+
+    def digest(self):
+        out = np.zeros(self.cfg.arenas, dtype=np.uint64)
+        self.L.sfo_state_digest(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return out
+
+    def dump(self, arena):
+        return dump_with(self.L.sfo_dump_arena, self.h, self.cfg, arena)
+
+    def draws(self, arena):
+        return self.L.sfo_draws(self.h, arena)
