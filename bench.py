@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched StrikeForce arena simulator on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch: every arena of every rank advances one iteration of
+the reference loop (gameplay.hpp:1443-1472).  Workload = BASELINE.json configs[1]: 4096 arenas per GPU,
+64x64 map, 1 player + 16 zombies, Solo, random-action agent; arenas are sharded across
+ranks with no data-path collective ("weak" scaling: 4096 arenas per GPU); the only collective is the RCCL
+all-gather of the end-of-episode result records after each launch.  Commands are resident in HBM before
+the timed region.  One JSON line is printed by rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def algorithmic_bytes_per_step(cfg, observe=False):
+    """SURVEY.md §8(d) contract figure per arena-step (caps used for live counts)."""
+    H, Z, B, A = cfg.cap_humans, cfg.cap_zombies, cfg.cap_bullets, cfg.n_agents
+    b = 2 * (128 * H + 16 * Z + 32 * B) + 2 * 80 + 16 * 8 * (H + Z) + 2 * 2 * 8 * 2 * B
+    if observe:
+        b += A * (123008 + 961 * 8)
+    return b
+
+
+def cpu_baseline(workload_name, seconds=12.0):
+    """The oracle (a single-threaded CPU port of the reference loop) timed on this host, on a bounded sample:
+    64 arenas of the same workload, as many 250-step rounds as fit in ~`seconds`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from strikeforce_amd import config
+    arenas = 64
+    w = config.baseline_workload(workload_name, arenas=arenas)
+    o = oracle_lib.Oracle(w)
+    tb, sr = w.seeds()
+    o.reset(tb, sr)
+    lcg = (C.c_uint32 * (arenas * w.cfg.n_agents))(*[12345 + i for i in range(arenas * w.cfg.n_agents)])
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        steps += o.L.sfo_bench_run(o.h, 250, lcg)
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d arenas of %s, %d arena-steps in %.1f s, oracle/sf_oracle.c single thread"
+                      % (arenas, workload_name, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--arenas", type=int, default=4096, help="arenas per GPU")
+    ap.add_argument("--k-per-launch", type=int, default=50, help="loop iterations per kernel launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from strikeforce_amd import config, env
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the simulator has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    w = config.baseline_workload(args.workload, arenas=args.arenas, device=local)
+    cfg = w.cfg
+    g = env.ArenaBatch(w)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    tb, sr = w.seeds(first_arena=rank * args.arenas)
+    g.reset(tb, sr)
+
+    total = args.warmup + args.steps
+    cmds, _ = config.bench_commands(args.arenas, cfg.n_agents, total, seed0=12345 + rank * args.arenas * cfg.n_agents)
+    d_cmds = torch.from_numpy(cmds).cuda()  # resident in HBM before the timed region
+    stride = args.arenas * cfg.n_agents
+    res_local = torch.zeros(args.arenas * cfg.n_agents * 8, dtype=torch.int32, device="cuda")
+    res_all = torch.zeros(world * res_local.numel(), dtype=torch.int32, device="cuda") if world > 1 else None
+
+    def run(first, count):
+        s = first
+        while s < first + count:
+            k = min(args.k_per_launch, first + count - s)
+            g.step_device(d_cmds.data_ptr() + s * stride, k)
+            if world > 1:  # end-of-episode result records, RCCL over xGMI
+                g.results_device(res_local.data_ptr())
+                dist.all_gather_into_tensor(res_all, res_local)
+            s += k
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    g.kernel_time(True)  # start timing step launches with HIP events on the launch stream
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k_ms, k_launches = g.kernel_time(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        env_steps = world * args.arenas * args.steps
+        bytes_step = algorithmic_bytes_per_step(cfg)
+        avg_launch_s = (k_ms / 1e3) / max(1, k_launches)
+        steps_per_launch = args.steps / max(1, k_launches)
+        achieved = bytes_step * args.arenas * steps_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node), 64x64 map x32 entities",
+            "value": env_steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] (%s): %d arenas/GPU, %dx%d map, %d human + %d zombie + %d bullet"
+                                   " slots, Solo level %d, random-action agent"
+                                   % (args.workload, args.arenas, cfg.rows, cfg.cols, cfg.cap_humans, cfg.cap_zombies,
+                                      cfg.cap_bullets, cfg.level),
+                       "arenas_per_gpu": args.arenas, "steps_per_launch": args.k_per_launch,
+                       "parallelism": "arena-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_step", "launches": k_launches, "avg_launch_ms": avg_launch_s * 1e3,
+                         "algorithmic_bytes_per_arena_step": bytes_step},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

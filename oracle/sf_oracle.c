@@ -395,7 +395,6 @@ static void o_human_damage(sfo_env *e, oarena *a, onode *pix) {
   b->alive = 0;
   if (h->hp <= 0) {
     h->alive = 0;
-    h->ctrl = 0; /* deleteAgent G:648-649 */
     SSET(pix, S_HUMAN, me == h);
     if (owner && owner->team == me->team && h->team != me->team) {
       ++a->teams_kills, a->loot += 100;

@@ -1,0 +1,1027 @@
+// sf_core.hpp — one arena per 64-lane wavefront: the per-tick gameplay path of the reference
+// (StrikeForce-client/gameplay.hpp:1443-1472 and everything it calls) on struct-of-arrays state.
+//
+// Execution model.  One wavefront owns one arena.  Entities live in registers, one lane per entity
+// slot (humans, zombies, portals: lane = slot; bullets: NB registers per lane, slot = j*64 + lane).
+// The only per-cell storage is one flag byte per cell, staged in LDS for the duration of a launch.
+// "Who is on cell q?" is answered by a lane compare + wavefront ballot instead of a pointer grid;
+// phases whose order matters in the reference (RNG draw order, slot-order sweeps, last-entrant-wins)
+// run as wave-uniform loops over ballot bit masks, and everything else runs lane-parallel.
+//
+// The file is a template over a wave backend W (per-lane value type V, predicate type P, ballot,
+// readlane, DPP reductions, LDS/global access).  The product instantiates it with WaveGfx950
+// (wave_gfx950.hpp); tests/emu instantiates the same source with a 64-lane CPU emulator so that the
+// kernel logic can be checked against the oracle (and under ASan) on machines without a GPU.
+// SF_DEV is defined by the backend header included before this file.
+//
+// Citations: G = gameplay.hpp, CH = Character.hpp, IT = Item.hpp, RN = random.hpp.
+#pragma once
+#include "../../include/strikeforce.h"
+#include "sf_types.hpp"
+
+namespace sf {
+
+enum { SH_WALL, SH_HUMAN, SH_ZOMBIE, SH_PUP, SH_PDN, SH_BULLET, SH_CHEST, SH_POUT, SH_EMPTY };
+enum { LIM_PORTAL = 1000, LIM_BLOCK = 1100 };  // G:37
+
+template <class W, int NB>
+struct Core {
+  using V = typename W::V;
+  using P = typename W::P;
+
+  struct Arena {
+    // humans (lane < H)
+    V hpos, hfl, hhp, hst, hmd, hk, hdm, hef, hc01, hc23, ht01, ht23, hbpk, hcmd;
+    // zombies (lane < Z)
+    V zpos, zhp, zmd;
+    // bullets (slot = j * 64 + lane)
+    V ba[NB], bd[NB], bb[NB], bc[NB];
+    // portals (lane < P)
+    V ppos;
+    // RNG (lane < 18): random[i], us[i], seed[i]  RN:31
+    V rv, rus, rseed;
+    // wave-uniform scalars  G:461
+    int32_t frame, kills, tkills, loot, chests, steps, episodes, done, outcome, ended;
+    uint32_t jomle, draws;
+    uint32_t tb_lo, tb_hi, sr_lo, sr_hi;
+    uint32_t dirty;  // the LDS flag plane differs from HBM
+  };
+
+  // ------------------------------------------------------------------------------------------------
+  // RNG: 18-tap generator over Z/65537, RN:27-77.  Taps are lane-parallel, the mod-exp is wave-uniform.
+  static SF_DEV uint32_t mulmod_u(uint32_t a, uint32_t b) {  // a, b in [0, 65536]
+    uint32_t p = a * b;                                      // wraps only for 65536*65536 = 2^32 == 1 (mod 65537)
+    int32_t r = (int32_t)(p & 0xffffu) - (int32_t)(p >> 16) + (int32_t)((a & b) >> 16);
+    r += (r >> 31) & 65537;
+    return (uint32_t)r;
+  }
+  static SF_DEV V mulmod_v(V a, V b) {
+    V p = a * b;
+    V r = (p & 0xffffu) - (p >> 16) + ((a & b) >> 16);
+    return r + (W::sar31(r) & 65537u);
+  }
+
+  static SF_DEV uint32_t draw(Arena &S) {  // RN:54-62
+    V x = S.rv;
+    V x2 = mulmod_v(x, x), x4 = mulmod_v(x2, x2), x8 = mulmod_v(x4, x4);
+    V s = S.rseed;  // 1..10: p[random[i]][seed[i]] = random[i]^seed[i]
+    V r = W::select((s & 1u) != 0u, x, V(1u));
+    r = W::select((s & 2u) != 0u, mulmod_v(r, x2), r);
+    r = W::select((s & 4u) != 0u, mulmod_v(r, x4), r);
+    r = W::select((s & 8u) != 0u, mulmod_v(r, x8), r);
+    uint32_t sum = W::sum18(S.rus * r) + 1u;  // rus is 0 on lanes >= 18; sum < 2^24
+    int32_t t = (int32_t)(sum & 0xffffu) - (int32_t)(sum >> 16);
+    t += (t >> 31) & 65537;
+    if (t == 0) t = 1;  // binpow(sum + (int)(sum == 0), ...)
+    S.jomle += 1u;
+    uint32_t e = S.jomle & 0xffffu;  // b %= mod - 1
+    uint32_t res = 1u, a = (uint32_t)t;
+    while (e) {
+      if (e & 1u) res = mulmod_u(res, a);
+      a = mulmod_u(a, a);
+      e >>= 1;
+    }
+    S.rv = W::select(W::lane() == 17u, V(res), W::shl1(S.rv));  // the 17 swaps: rotate left, new value last
+    S.draws += 1u;
+    return res & 1023u;
+  }
+
+  static SF_DEV void srand_(Arena &S, uint64_t tb, uint64_t us) {  // RN:64-76
+    S.rv = V(0u), S.rus = V(0u), S.rseed = V(0u);
+    for (int i = 0; i < 18; ++i) {
+      W::setlane(S.rus, (uint32_t)i, (uint32_t)(us % 10u) + 1u);
+      W::setlane(S.rseed, (uint32_t)i, (uint32_t)(tb % 10u) + 1u);
+      us /= 10u;
+      tb /= 10u;
+    }
+    S.jomle = 18u;
+    for (int i = 0; i < 1024; ++i) draw(S);
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // cell queries (q wave-uniform)
+  static SF_DEV int DX(int d) { return d == 0 ? 1 : (d == 2 ? -1 : 0); }  // wdx CH:47
+  static SF_DEV int DY(int d) { return d == 1 ? 1 : (d == 3 ? -1 : 0); }  // wdy
+  static SF_DEV uint32_t cellidx(const Params &p, int f, int r, int c) { return (uint32_t)((f * p.N + r) * p.M + c); }
+  static SF_DEV uint32_t cellidx_q(const Params &p, uint32_t q) { return cellidx(p, pos_f(q), pos_r(q), pos_c(q)); }
+  static SF_DEV bool inmap(const Params &p, int r, int c) {
+    return (uint32_t)r < (uint32_t)p.N && (uint32_t)c < (uint32_t)p.M;
+  }
+  // Out-of-range cells read as indestructible wall (the reference reads without bounds checks in
+  // zombie_action / update_bull / portal_damage and relies on border walls).
+  static SF_DEV uint32_t flags_at(const uint8_t *lds, const Params &p, int f, int r, int c) {
+    if (!inmap(p, r, c)) return SF_CELL_WALL;
+    return W::ulds_u8(lds, cellidx(p, f, r, c));
+  }
+  static SF_DEV int human_at(const Arena &S, uint32_t q) {  // the human designated by the cell's s[0]
+    uint64_t m = W::ballot(((S.hfl & HF_OCC) != 0u) & (S.hpos == q));
+    return m ? W::ctz64(m) : -1;
+  }
+  static SF_DEV int live_human_at(const Arena &S, uint32_t q) {
+    uint64_t m = W::ballot(((S.hfl & HF_ALIVE) != 0u) & (S.hpos == q));
+    return m ? W::ctz64(m) : -1;
+  }
+  static SF_DEV int zombie_at(const Arena &S, uint32_t q) {
+    uint64_t m = W::ballot((S.zpos & (ZF_ALIVE | POS_MASK)) == (ZF_ALIVE | q));
+    return m ? W::ctz64(m) : -1;
+  }
+  static SF_DEV int refbullet_at(const Arena &S, uint32_t q) {  // the bullet designated by the cell's s[2]
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      uint64_t m = W::ballot((S.ba[j] & (BA_REF | POS_MASK)) == (BA_REF | q));
+      if (m) return j * 64 + W::ctz64(m);
+    }
+    return -1;
+  }
+  // node::showit() G:321-346 as a class code
+  static SF_DEV int showit(const Arena &S, const uint8_t *lds, const Params &p, int f, int r, int c, uint32_t &fl) {
+    fl = flags_at(lds, p, f, r, c);
+    if (fl & SF_CELL_WALL) return SH_WALL;
+    const uint32_t q = pos_pack(f, r, c);
+    if (human_at(S, q) >= 0) return SH_HUMAN;
+    if (zombie_at(S, q) >= 0) return SH_ZOMBIE;
+    if (fl & SF_CELL_PIN_UP) return SH_PUP;
+    if (fl & SF_CELL_PIN_DN) return SH_PDN;
+    if (refbullet_at(S, q) >= 0) return SH_BULLET;
+    if (fl & SF_CELL_CHEST) return SH_CHEST;
+    if (fl & SF_CELL_POUT) return SH_POUT;
+    return SH_EMPTY;
+  }
+  static SF_DEV int showit_q(const Arena &S, const uint8_t *lds, const Params &p, uint32_t q, uint32_t &fl) {
+    return showit(S, lds, p, pos_f(q), pos_r(q), pos_c(q), fl);
+  }
+  // `(sit != '#' && sit != 'v' && sit != '^') || s[10]`  G:812,1086
+  static SF_DEV bool bullet_may_enter(int sit, uint32_t fl) {
+    return (sit != SH_WALL && sit != SH_PDN && sit != SH_PUP) || (fl & SF_CELL_TEMP);
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // slot allocators G:209-235
+  static SF_DEV uint64_t capmask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+  static SF_DEV int b_ind(const Arena &S, const Params &p) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      int left = p.B - 64 * j;
+      if (left > 0) {
+        uint64_t fr = ~W::ballot((S.ba[j] & BA_ALIVE) != 0u) & capmask(left);
+        if (fr) return j * 64 + W::ctz64(fr);
+      }
+    }
+    return -1;
+  }
+  static SF_DEV int z_ind(const Arena &S, const Params &p) {
+    uint64_t fr = ~W::ballot((S.zpos & ZF_ALIVE) != 0u) & capmask(p.Z);
+    return fr ? W::ctz64(fr) : -1;
+  }
+  static SF_DEV int h_ind(const Arena &S, const Params &p) {  // skips `ind` (= slot 0) and remote slots
+    uint64_t fr = ~W::ballot((S.hfl & (HF_ALIVE | HF_REMOTE)) != 0u) & capmask(p.H) & ~1ull;
+    return fr ? W::ctz64(fr) : -1;
+  }
+  static SF_DEV int p_ind(const Arena &S, const Params &p) {
+    uint64_t fr = ~W::ballot((S.ppos & PF_ACTIVE) != 0u) & capmask(p.P);
+    return fr ? W::ctz64(fr) : -1;
+  }
+
+  // Activate bullet slot `idx` on cell q and make it the cell's designated bullet (Bullet::shot IT:156-163
+  // + `pix->bullet = &bull[index]; pix->s[2] = 1; mb[index] = true`).  A bullet already designated there
+  // is orphaned.
+  static SF_DEV void bullet_put(Arena &S, int idx, uint32_t q, int way, int dmg, int eff, int range, int owner) {
+    const uint32_t l = (uint32_t)idx & 63u;
+    const uint32_t a = q | ((uint32_t)(way - 1) << BA_WAY_SH) | BA_ALIVE | BA_REF;
+    const uint32_t b = ((uint32_t)eff & 0xffffu) | ((uint32_t)owner << 16);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      S.ba[j] = W::select((S.ba[j] & (BA_REF | POS_MASK)) == (BA_REF | q), S.ba[j] & ~BA_REF, S.ba[j]);
+      if (j == (idx >> 6)) {
+        W::setlane(S.ba[j], l, a);
+        W::setlane(S.bd[j], l, (uint32_t)dmg);
+        W::setlane(S.bb[j], l, b);
+        W::setlane(S.bc[j], l, (uint32_t)range);
+      }
+    }
+  }
+  static SF_DEV void bullet_kill(Arena &S, int idx) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (j == (idx >> 6)) W::setlane(S.ba[j], (uint32_t)idx & 63u, 0u);
+  }
+  static SF_DEV uint32_t bullet_word(const V (&w)[NB], int idx) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (j == (idx >> 6)) r = W::readlane(w[j], (uint32_t)idx & 63u);
+    return r;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // human field helpers (wave-uniform access to slot i)
+  static SF_DEV int h_way(uint32_t fl) { return (int)(fl & HF_WAY_MASK); }
+  static SF_DEV int h_team(uint32_t fl) { return (int)((fl >> HF_TEAM_SH) & 255u); }
+  static SF_DEV int h_vec(uint32_t fl) { return (int)((fl >> HF_VEC_SH) & 3u) - 1; }
+  static SF_DEV int h_sel(uint32_t fl) { return (int)((fl >> HF_IND_SH) & 15u) - 1; }
+  static SF_DEV int h_prof(uint32_t fl) { return (fl & HF_PROF) ? 1 : 0; }
+  static SF_DEV uint32_t set_vec_sel(uint32_t fl, int vec, int sel) {
+    fl &= ~((3u << HF_VEC_SH) | (15u << HF_IND_SH));
+    return fl | ((uint32_t)(vec + 1) << HF_VEC_SH) | ((uint32_t)(sel + 1) << HF_IND_SH);
+  }
+  static SF_DEV uint32_t get16(const V &lo, const V &hi, uint32_t lane, int k) {  // k in 0..3
+    uint32_t w = W::readlane(k < 2 ? lo : hi, lane);
+    return (w >> ((k & 1) * 16)) & 0xffffu;
+  }
+  static SF_DEV void set16(V &lo, V &hi, uint32_t lane, int k, uint32_t val) {
+    const int sh = (k & 1) * 16;
+    if (k < 2) {
+      uint32_t w = W::readlane(lo, lane);
+      W::setlane(lo, lane, (w & ~(0xffffu << sh)) | ((val & 0xffffu) << sh));
+    } else {
+      uint32_t w = W::readlane(hi, lane);
+      W::setlane(hi, lane, (w & ~(0xffffu << sh)) | ((val & 0xffffu) << sh));
+    }
+  }
+  static SF_DEV void add_lane(V &v, uint32_t lane, int32_t d) {
+    W::setlane(v, lane, W::readlane(v, lane) + (uint32_t)d);
+  }
+
+  // Build a fresh human of profile `prof` in slot i (Human::build CH:650-709 / gen_human CH:873-888).
+  static SF_DEV void human_make(Arena &S, const Params &p, uint32_t i, int prof, uint32_t q, int way, int team,
+                                uint32_t extra_flags) {
+    const Derived &d = p.tab->der[prof];
+    W::setlane(S.hpos, i, q);
+    uint32_t fl = (uint32_t)way | ((uint32_t)team << HF_TEAM_SH) | HF_ALIVE | HF_OCC | (prof ? HF_PROF : 0u) | extra_flags;
+    W::setlane(S.hfl, i, set_vec_sel(fl, -1, -1));
+    W::setlane(S.hhp, i, (uint32_t)d.hp);
+    W::setlane(S.hst, i, (uint32_t)d.stamina);
+    W::setlane(S.hmd, i, (uint32_t)d.mindamage);
+    W::setlane(S.hk, i, 0u), W::setlane(S.hdm, i, 0u), W::setlane(S.hef, i, 0u);
+    W::setlane(S.hc01, i, (uint32_t)d.cons[0] | ((uint32_t)d.cons[1] << 16));
+    W::setlane(S.hc23, i, (uint32_t)d.cons[2] | ((uint32_t)d.cons[3] << 16));
+    W::setlane(S.ht01, i, (uint32_t)d.thr_cnt[0] | ((uint32_t)d.thr_cnt[1] << 16));
+    W::setlane(S.ht23, i, (uint32_t)d.thr_cnt[2] | ((uint32_t)d.thr_cnt[3] << 16));
+    W::setlane(S.hbpk, i, (uint32_t)d.blocks | ((uint32_t)d.portals << 8));  // portal_ind = -1
+    W::setlane(S.hcmd, i, (uint32_t)'+');
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // spawns G:532-572 (loop top G:1444-1449)
+  static SF_DEV void spawn_chest(Arena &S, uint8_t *lds, const Params &p) {
+    if (p.C <= S.chests) return;
+    int i = (int)(draw(S) % (uint32_t)p.F), j = (int)(draw(S) % (uint32_t)p.N), k = (int)(draw(S) % (uint32_t)p.M);
+    uint32_t fl;
+    if (showit(S, lds, p, i, j, k, fl) != SH_EMPTY) return;
+    uint32_t t = draw(S) % 4u;
+    W::ulds_store_u8(lds, cellidx(p, i, j, k), fl | SF_CELL_CHEST | (t << SF_CELL_CONS_SHIFT));
+    S.dirty = 1u;
+    ++S.chests;
+  }
+  static SF_DEV void spawn_zombie_npc(Arena &S, uint8_t *lds, const Params &p) {
+    int i = (int)(draw(S) % (uint32_t)p.F), j = (int)(draw(S) % (uint32_t)p.N), k = (int)(draw(S) % (uint32_t)p.M);
+    uint32_t fl;
+    if (showit(S, lds, p, i, j, k, fl) != SH_EMPTY) return;
+    int index = z_ind(S, p);
+    if (index == -1) return;
+    uint32_t super_ = (draw(S) % 4u == 0u) ? 1u : 0u;  // Zombie::gen_npc CH:850-857
+    W::setlane(S.zpos, (uint32_t)index, pos_pack(i, j, k) | ZF_ALIVE | (super_ ? ZF_SUPER : 0u));
+    W::setlane(S.zhp, (uint32_t)index, (super_ + 1u) * 400u);
+    W::setlane(S.zmd, (uint32_t)index, (super_ + 1u) * 100u);
+  }
+  static SF_DEV void spawn_human_npc(Arena &S, uint8_t *lds, const Params &p) {
+    int i = (int)(draw(S) % (uint32_t)p.F), j = (int)(draw(S) % (uint32_t)p.N), k = (int)(draw(S) % (uint32_t)p.M);
+    uint32_t fl;
+    if (showit(S, lds, p, i, j, k, fl) != SH_EMPTY) return;
+    int index = h_ind(S, p);
+    if (index == -1) return;
+    human_make(S, p, (uint32_t)index, 1, pos_pack(i, j, k), 1, 0, HF_RNPC);
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // zombie_action G:654-693: slot-ordered, wave-uniform loop over live zombies
+  static SF_DEV void zombie_action(Arena &S, uint8_t *lds, const Params &p) {
+    uint64_t zm = W::ballot((S.zpos & ZF_ALIVE) != 0u) & capmask(p.Z);
+    while (zm) {
+      const uint32_t z = (uint32_t)W::ctz64(zm);
+      zm &= zm - 1ull;
+      const uint32_t zp = W::readlane(S.zpos, z);
+      const uint32_t q0 = zp & POS_MASK;
+      const int f = pos_f(q0), r = pos_r(q0), c = pos_c(q0);
+      if (refbullet_at(S, q0) >= 0) continue;
+      bool b = false;
+      // one ballot decides the common "no human next to me" case; the packed compare of an
+      // out-of-range neighbour (row/col -1) matches nobody
+      const P occ = (S.hfl & HF_OCC) != 0u;
+      const uint64_t near = W::ballot(occ & ((S.hpos == q0 + 1024u) | (S.hpos == q0 + 1u) | (S.hpos == q0 - 1024u) |
+                                             (S.hpos == q0 - 1u)));
+      if (near) {
+        const int zmd = (int)W::readlane(S.zmd, z);
+        for (int i1 = 0; i1 < 4; ++i1) {
+          const int rr = r + DX(i1), cc = c + DY(i1);
+          if (!inmap(p, rr, cc)) continue;
+          const uint32_t q = pos_pack(f, rr, cc);
+          if (human_at(S, q) >= 0) {
+            int index = b_ind(S, p);
+            if (refbullet_at(S, q) < 0 && index != -1)  // Zombie::punch CH:838-844
+              bullet_put(S, index, q, i1 + 1, zmd > 0 ? zmd : 0, 0, 1, 0);
+            b = true;
+          }
+        }
+      }
+      if (!b) {
+        if (draw(S) % 5u < 2u) continue;
+        for (int i1 = 0; i1 < 2; ++i1) {
+          const int i2 = (int)(draw(S) % 4u);
+          uint32_t fl;
+          if (showit(S, lds, p, f, r + DX(i2), c + DY(i2), fl) == SH_EMPTY) {
+            W::setlane(S.zpos, z, (zp & ~POS_MASK) | pos_pack(f, r + DX(i2), c + DY(i2)));
+            break;
+          }
+        }
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // portal_damage G:1279-1297
+  static SF_DEV void portal_damage(Arena &S, uint8_t *lds, const Params &p) {
+    uint64_t pm = W::ballot((S.ppos & PF_ACTIVE) != 0u) & capmask(p.P);
+    while (pm) {
+      const uint32_t i = (uint32_t)W::ctz64(pm);
+      pm &= pm - 1ull;
+      const uint32_t q = W::readlane(S.ppos, i) & POS_MASK;
+      uint32_t fl;
+      if (showit_q(S, lds, p, q, fl) != SH_POUT) {
+        int index = b_ind(S, p);
+        if (index == -1) return;
+        bullet_put(S, index, q, 3, 20, -10, 1, 0);  // radiation.ready(20, -10, 1); shot(v, 3, radiation, 0)
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // update_tmp G:1343-1381.  Bullets standing on destructible '#' / '^' cells are absorbed; objects whose
+  // accumulated damage crossed the limit are removed.  Only a cell that absorbed a bullet in this call can
+  // cross its limit in this call, so the reference's sweep over `temp` reduces to those cells.
+  static SF_DEV void break_if_spent(Arena &S, uint8_t *lds, const Params &p, int a, uint32_t q) {
+    uint32_t fl;
+    const int sit = showit_q(S, lds, p, q, fl);
+    if (!(fl & SF_CELL_TEMP)) return;
+    const uint32_t ci = cellidx_q(p, q);
+    int32_t *dmg = p.aux_dmg + (size_t)a * (size_t)p.cells;
+    const int32_t d = W::uload_i32(dmg + ci);
+    if (sit == SH_PUP && d >= LIM_PORTAL) {
+      const int i = (int)W::uload_i16(p.aux_pidx + (size_t)a * (size_t)p.cells + ci);
+      const uint32_t e1 = W::readlane(S.ppos, (uint32_t)i) & POS_MASK;
+      const uint32_t c1 = cellidx_q(p, e1);
+      W::ulds_store_u8(lds, c1, W::ulds_u8(lds, c1) & ~(uint32_t)(SF_CELL_POUT | SF_CELL_TEMP));
+      W::ulds_store_u8(lds, ci, fl & ~(uint32_t)(SF_CELL_PIN_UP | SF_CELL_TEMP));
+      W::ustore_i32(dmg + ci, 0);
+      W::setlane(S.ppos, (uint32_t)i, 0u);
+      S.dirty = 1u;
+    } else if (sit == SH_WALL && d >= LIM_BLOCK) {
+      W::ulds_store_u8(lds, ci, fl & ~(uint32_t)(SF_CELL_WALL | SF_CELL_TEMP));
+      W::ustore_i32(dmg + ci, 0);
+      S.dirty = 1u;
+    }
+  }
+
+  static SF_DEV void update_tmp(Arena &S, uint8_t *lds, const Params &p, int a) {
+    uint64_t cand[NB];
+    V cell[NB];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const P alive = (S.ba[j] & BA_ALIVE) != 0u;
+      cell[j] = S.ba[j] & POS_MASK;
+      const V ci = ((cell[j] >> 20) * (uint32_t)p.N + ((cell[j] >> 10) & 1023u)) * (uint32_t)p.M + (cell[j] & 1023u);
+      const V fl = W::lds_u8(lds, ci, alive);
+      cand[j] = W::ballot(alive & ((fl & SF_CELL_TEMP) != 0u) & ((fl & (SF_CELL_WALL | SF_CELL_PIN_UP)) != 0u));
+      any = any || cand[j] != 0ull;
+    }
+    if (!any) return;
+    int32_t *dmg = p.aux_dmg + (size_t)a * (size_t)p.cells;
+    // pass 1, slot order: absorb.  `s[2] = 0` un-designates the cell's bullet; every bullet standing on
+    // this cell is absorbed by this same loop, so clearing each absorbed bullet's own flags is equivalent.
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      uint64_t m = cand[j];
+      while (m) {
+        const uint32_t l = (uint32_t)W::ctz64(m);
+        m &= m - 1ull;
+        const uint32_t q = W::readlane(cell[j], l);
+        uint32_t fl;
+        const int sit = showit_q(S, lds, p, q, fl);
+        if (sit == SH_PUP || sit == SH_WALL) {
+          const uint32_t ci = cellidx_q(p, q);
+          W::ustore_i32(dmg + ci, W::uload_i32(dmg + ci) + (int32_t)W::readlane(S.bd[j], l));
+          W::setlane(S.ba[j], l, 0u);
+        } else {
+          cand[j] &= ~(1ull << l);  // a human / zombie stands on the '^': the bullet hits them instead
+        }
+      }
+    }
+    // pass 2: `for(auto e: temp)` restricted to the cells that took damage (idempotent per cell)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      uint64_t m = cand[j];
+      while (m) {
+        const uint32_t l = (uint32_t)W::ctz64(m);
+        m &= m - 1ull;
+        break_if_spent(S, lds, p, a, W::readlane(cell[j], l));
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // hit_human + hit_zombie G:574-652.  A cell holds at most one character and a hit consumes only the
+  // cell's designated bullet, so the two slot-ordered sweeps reduce to: (1) humans already at Hp <= 0 die
+  // (lane-parallel); (2) one wave-uniform pass over designated bullets that share a cell with a live
+  // character.  All cross-entity effects are additive (owner damage/effect/kills, loot, kill counters).
+  static SF_DEV void hits(Arena &S) {
+    {
+      const P dying = ((S.hfl & HF_ALIVE) != 0u) & W::le0(S.hhp);                  // G:641-645
+      // s[0] = (human == &hum[ind]); deleteAgent() only for i != ind  G:643,648-649
+      S.hfl = W::select(dying, W::select(W::lane() == 0u, S.hfl & ~HF_ALIVE, S.hfl & ~(HF_ALIVE | HF_CTRL | HF_OCC)), S.hfl);
+    }
+    const uint32_t my_team = (uint32_t)h_team(W::readlane(S.hfl, 0u));
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      uint64_t m = W::ballot((S.ba[j] & BA_REF) != 0u);
+      while (m) {
+        const uint32_t l = (uint32_t)W::ctz64(m);
+        m &= m - 1ull;
+        const uint32_t q = W::readlane(S.ba[j], l) & POS_MASK;
+        const int hv = live_human_at(S, q);
+        const int zv = hv >= 0 ? -1 : zombie_at(S, q);
+        if (hv < 0 && zv < 0) continue;
+        const int32_t dmg = (int32_t)W::readlane(S.bd[j], l);
+        const uint32_t bb = W::readlane(S.bb[j], l);
+        const int32_t eff = (int32_t)(int16_t)(bb & 0xffffu);
+        const int owner = (int)(bb >> 16);  // human slot + 1, 0 = none
+        W::setlane(S.ba[j], l, 0u);        // pix->s[2] = 0; mb[...] = false
+        const uint32_t ofl = owner ? W::readlane(S.hfl, (uint32_t)(owner - 1)) : 0u;
+        const uint32_t owner_team = (uint32_t)h_team(ofl);
+        if (hv >= 0) {  // human_damage G:611-634
+          const uint32_t vfl = W::readlane(S.hfl, (uint32_t)hv);
+          const uint32_t vteam = (uint32_t)h_team(vfl);
+          const int32_t hp = (int32_t)W::readlane(S.hhp, (uint32_t)hv) - dmg;  // Character::hit CH:242-246
+          W::setlane(S.hhp, (uint32_t)hv, (uint32_t)hp);
+          add_lane(S.hmd, (uint32_t)hv, eff);
+          const bool cross = owner && vteam != owner_team;
+          if (cross) {
+            add_lane(S.hdm, (uint32_t)(owner - 1), dmg);
+            add_lane(S.hef, (uint32_t)(owner - 1), eff);
+          }
+          if (hp <= 0) {
+            W::setlane(S.hfl, (uint32_t)hv, hv == 0 ? (vfl & ~HF_ALIVE) : (vfl & ~(HF_ALIVE | HF_CTRL | HF_OCC)));
+            if (owner && owner_team == my_team && vteam != my_team) {
+              ++S.tkills, S.loot += 100;
+              if (owner == 1) S.loot += 900, ++S.kills;
+            }
+            if (cross) add_lane(S.hk, (uint32_t)(owner - 1), 1);
+          }
+        } else {  // zombie_damage G:574-598
+          const uint32_t zp = W::readlane(S.zpos, (uint32_t)zv);
+          const int32_t hp = (int32_t)W::readlane(S.zhp, (uint32_t)zv) - dmg;
+          W::setlane(S.zhp, (uint32_t)zv, (uint32_t)hp);
+          add_lane(S.zmd, (uint32_t)zv, eff);
+          if (owner) {
+            add_lane(S.hdm, (uint32_t)(owner - 1), dmg);
+            add_lane(S.hef, (uint32_t)(owner - 1), eff);
+          }
+          if (hp <= 0) {
+            W::setlane(S.zpos, (uint32_t)zv, 0u);
+            if (owner && owner_team == my_team) {
+              const int pts = 500 + ((zp & ZF_SUPER) ? 250 : 0);
+              ++S.tkills, S.loot += pts / 10;
+              if (owner == 1) S.loot += pts * 9 / 10, ++S.kills;
+            }
+            if (owner) add_lane(S.hk, (uint32_t)(owner - 1), 1);
+          }
+        }
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // update_bull G:1059-1100.  Expiry / advance is lane-parallel; "the last bullet to enter a cell becomes
+  // the cell's designated bullet" is resolved per distinct destination with ballots.
+  static SF_DEV void update_bull(Arena &S, uint8_t *lds, const Params &p) {
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) any = any || W::ballot((S.ba[j] & BA_ALIVE) != 0u) != 0ull;
+    const uint32_t r = draw(S) & 1u;  // drawn even when no bullet is alive
+    if (!any) return;
+    uint64_t moved[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const P alive = (S.ba[j] & BA_ALIVE) != 0u;
+      const V range = S.bc[j] & 0xffffu, trav = S.bc[j] >> 16;
+      const P live = alive & W::ltu(trav + 1u, range);  // Bullet::expire IT:165-168: dist + 1 >= range
+      const V q = S.ba[j] & POS_MASK;
+      const V d = (S.ba[j] >> BA_WAY_SH) & 3u;
+      const V rr = ((q >> 10) & 1023u) + W::select(d == 0u, V(1u), W::select(d == 2u, V(0xffffffffu), V(0u)));
+      const V cc = (q & 1023u) + W::select(d == 1u, V(1u), W::select(d == 3u, V(0xffffffffu), V(0u)));
+      const P inb = live & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
+      const V ci = ((q >> 20) * (uint32_t)p.N + rr) * (uint32_t)p.M + cc;
+      const V fl = W::lds_u8(lds, ci, inb);
+      const P temp = (fl & SF_CELL_TEMP) != 0u, wall = (fl & SF_CELL_WALL) != 0u,
+              pin = (fl & (SF_CELL_PIN_UP | SF_CELL_PIN_DN)) != 0u;
+      const V nq = (q & (3u << 20)) | (rr << 10) | cc;
+      // a '^' / 'v' cell shows the character standing on it instead (showit order), which lets bullets in
+      uint64_t amb = W::ballot(inb & (!temp) & (!wall) & pin);
+      uint64_t covered = 0ull;
+      while (amb) {
+        const uint32_t l = (uint32_t)W::ctz64(amb);
+        amb &= amb - 1ull;
+        const uint32_t qq = W::readlane(nq, l);
+        if (human_at(S, qq) >= 0 || zombie_at(S, qq) >= 0) covered |= 1ull << l;
+      }
+      const P pass = inb & (temp | ((!wall) & ((!pin) | W::frombits(covered))));
+      moved[j] = W::ballot(pass);
+      // survivors advance and lose their designation; everything else that was alive dies
+      const V na = (S.ba[j] & ~(POS_MASK | BA_REF)) | nq;
+      S.ba[j] = W::select(pass, na, V(0u));
+      S.bc[j] = W::select(pass, S.bc[j] + 0x10000u, S.bc[j]);
+    }
+    // designation: r = 1 sweeps slots ascending (last entrant = highest slot), r = 0 descending
+#pragma unroll
+    for (int j0 = 0; j0 < NB; ++j0) {
+      while (moved[j0]) {
+        const uint32_t l = (uint32_t)W::ctz64(moved[j0]);
+        uint32_t q = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (j == j0) q = W::readlane(S.ba[j], l) & POS_MASK;
+        uint64_t same[NB];
+        int win = -1;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          same[j] = W::ballot(((S.ba[j] & BA_ALIVE) != 0u) & ((S.ba[j] & POS_MASK) == q)) & moved[j];
+          moved[j] &= ~same[j];
+        }
+        if (r) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            if (same[j]) win = j * 64 + 63 - W::clz64(same[j]);
+        } else {
+#pragma unroll
+          for (int j = NB - 1; j >= 0; --j)
+            if (same[j]) win = j * 64 + W::ctz64(same[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (j == (win >> 6)) W::setlane(S.ba[j], (uint32_t)win & 63u, W::readlane(S.ba[j], (uint32_t)win & 63u) | BA_REF);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // claim_chest G:507-515, teleport G:517-530
+  static SF_DEV void claim_chest(Arena &S, uint8_t *lds, const Params &p, uint32_t i) {
+    const uint32_t q = W::readlane(S.hpos, i);
+    const uint32_t ci = cellidx_q(p, q);
+    const uint32_t fl = W::ulds_u8(lds, ci);
+    if (fl & SF_CELL_CHEST) {
+      const int32_t *c = p.tab->cons_items[(fl >> SF_CELL_CONS_SHIFT) & 3u];  // Human::claim_chest CH:372-377
+      add_lane(S.hst, i, c[0]);
+      add_lane(S.hhp, i, c[1]);
+      add_lane(S.hmd, i, c[2]);
+      W::ulds_store_u8(lds, ci, fl & ~(uint32_t)(SF_CELL_CHEST | (3u << SF_CELL_CONS_SHIFT)));
+      S.dirty = 1u;
+      --S.chests;
+    }
+  }
+  static SF_DEV void teleport(Arena &S, uint8_t *lds, const Params &p, int a, uint32_t i) {
+    const uint32_t q = W::readlane(S.hpos, i);
+    const uint32_t ci = cellidx_q(p, q);
+    const uint32_t fl = W::ulds_u8(lds, ci);
+    if (!(fl & (SF_CELL_PIN_UP | SF_CELL_PIN_DN))) return;  // portal_ind == -1
+    const int index = (fl & SF_CELL_TEMP) ? (int)W::uload_i16(p.aux_pidx + (size_t)a * (size_t)p.cells + ci)
+                                          : (int)W::uload_i16(p.map_pidx + ci);
+    if (index < 0 || index >= p.P) return;
+    const uint32_t e = W::readlane(S.ppos, (uint32_t)index) & POS_MASK;
+    uint32_t efl;
+    if (showit_q(S, lds, p, e, efl) != SH_POUT) return;
+    W::setlane(S.hpos, i, e);
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // obey G:695-821 for human slot i (wave-uniform)
+  static SF_DEV void obey(Arena &S, uint8_t *lds, const Params &p, int a, uint32_t c, uint32_t i) {
+    if (c == '+') return;
+    const uint32_t fl0 = W::readlane(S.hfl, i);
+    const uint32_t q0 = W::readlane(S.hpos, i);
+    const int f = pos_f(q0), r = pos_r(q0), cc0 = pos_c(q0);
+    const int way = h_way(fl0);
+    if (c == '_') {
+      W::setlane(S.hhp, i, 0u);
+      return;
+    }
+    if (c == '[' || c == ']') {
+      const int rr = r + DX(way - 1), cc = cc0 + DY(way - 1);
+      if (!inmap(p, rr, cc)) return;
+      uint32_t fl;
+      if (showit(S, lds, p, f, rr, cc, fl) != SH_EMPTY) return;
+      const uint32_t ci = cellidx(p, f, rr, cc);
+      const uint32_t bp = W::readlane(S.hbpk, i);
+      const uint32_t blocks = bp & 255u, portals = (bp >> 8) & 255u;
+      const int pind = (int)((bp >> 16) & 255u) - 1;
+      int32_t *dmg = p.aux_dmg + (size_t)a * (size_t)p.cells;
+      if (c == '[') {
+        if (blocks) {
+          W::ulds_store_u8(lds, ci, fl | SF_CELL_TEMP | SF_CELL_WALL);
+          W::ustore_i32(dmg + ci, 0);
+          W::setlane(S.hbpk, i, bp - 1u);
+          S.dirty = 1u;
+        }
+        return;
+      }
+      if (pind != -1) {
+        W::ulds_store_u8(lds, ci, fl | SF_CELL_TEMP | SF_CELL_PIN_UP);
+        W::ustore_i32(dmg + ci, 0);
+        W::ustore_i16(p.aux_pidx + (size_t)a * (size_t)p.cells + ci, (int16_t)pind);
+        W::setlane(S.hbpk, i, bp & 0xffffu);
+        S.dirty = 1u;
+      } else if (portals) {
+        const int index = p_ind(S, p);
+        if (index == -1) return;
+        W::ulds_store_u8(lds, ci, fl | SF_CELL_TEMP | SF_CELL_POUT);
+        W::ustore_i32(dmg + ci, 0);
+        W::setlane(S.hbpk, i, (bp - 256u) | ((uint32_t)(index + 1) << 16));
+        W::setlane(S.ppos, (uint32_t)index, pos_pack(f, rr, cc) | PF_ACTIVE);
+        S.dirty = 1u;
+      }
+      return;
+    }
+    if (c == 'q' || c == 'e') {  // turn_l / turn_r CH:745-759
+      const int nw = c == 'e' ? (way == 1 ? 4 : way - 1) : (way == 4 ? 1 : way + 1);
+      W::setlane(S.hfl, i, (fl0 & ~HF_WAY_MASK) | (uint32_t)nw);
+      return;
+    }
+    if (c == 's' || c == 'd' || c == 'w' || c == 'a') {
+      const int d = c == 's' ? 0 : (c == 'd' ? 1 : (c == 'w' ? 2 : 3));
+      const int rr = r + DX(d), cc = cc0 + DY(d);
+      if (!inmap(p, rr, cc)) return;
+      uint32_t fl;
+      const int sit = showit(S, lds, p, f, rr, cc, fl);
+      if (sit == SH_CHEST || sit == SH_PUP || sit == SH_PDN || sit == SH_EMPTY || sit == SH_BULLET)
+        W::setlane(S.hpos, i, pos_pack(f, rr, cc));
+      return;
+    }
+    int k = -1;
+    if ((k = (c == 'f' ? 0 : c == 'g' ? 1 : c == 'h' ? 2 : c == 'j' ? 3 : -1)) >= 0) {
+      if (get16(S.hc01, S.hc23, i, k)) W::setlane(S.hfl, i, set_vec_sel(fl0, 0, k));
+      return;
+    }
+    if ((k = (c == 'k' ? 0 : c == 'l' ? 1 : c == ';' ? 2 : c == '\'' ? 3 : -1)) >= 0) {
+      if (get16(S.ht01, S.ht23, i, k)) W::setlane(S.hfl, i, set_vec_sel(fl0, 1, k));
+      return;
+    }
+    if ((k = (c == 'c' ? 0 : c == 'v' ? 1 : c == 'b' ? 2 : c == 'n' ? 3 : c == 'm' ? 4 : c == ',' ? 5 : c == '.' ? 6
+                                                                                              : c == '/' ? 7 : -1)) >= 0) {
+      if (p.tab->der[h_prof(fl0)].weapon_lvl[k]) W::setlane(S.hfl, i, set_vec_sel(fl0, 2, k));
+      return;
+    }
+    const int vec = h_vec(fl0), sel = h_sel(fl0);
+    if (c == 'u') {  // Human::use CH:379-389
+      if (vec != 0) return;
+      const uint32_t n = get16(S.hc01, S.hc23, i, sel);
+      if (n < 1u) return;
+      const int32_t *ci = p.tab->cons_items[sel];
+      add_lane(S.hst, i, ci[0]);
+      add_lane(S.hhp, i, ci[1]);
+      add_lane(S.hmd, i, ci[2]);
+      set16(S.hc01, S.hc23, i, sel, n - 1u);
+      if (n - 1u < 1u) W::setlane(S.hfl, i, set_vec_sel(fl0, -1, sel));
+      return;
+    }
+    if (c == 'z' || c == 'x') {
+      const int rr = r + DX(way - 1), cc = cc0 + DY(way - 1);
+      const int index = b_ind(S, p);
+      if (index == -1 || !inmap(p, rr, cc)) return;
+      const Derived &d = p.tab->der[h_prof(fl0)];
+      const int32_t md = (int32_t)W::readlane(S.hmd, i);
+      const int32_t st = (int32_t)W::readlane(S.hst, i);
+      bool can;
+      int dmg = 0, eff = 0, range = 1;
+      if (c == 'z') {  // Human::punch CH:391-397
+        dmg = d.cd_punch > md ? d.cd_punch : md;
+        can = true;
+      } else if (vec == 1) {  // Human::throw_it CH:410-427
+        const int32_t *t = d.thr[sel];
+        const uint32_t n = get16(S.ht01, S.ht23, i, sel);
+        dmg = t[1] > t[1] + md ? t[1] : t[1] + md;
+        eff = t[2], range = t[3];
+        if (st + t[0] < 0)
+          can = false;
+        else if (n < 1u) {
+          W::setlane(S.hfl, i, set_vec_sel(fl0, -1, sel));
+          can = false;
+        } else {
+          W::setlane(S.hst, i, (uint32_t)(st + t[0]));
+          set16(S.ht01, S.ht23, i, sel, n - 1u);
+          if (n - 1u < 1u) W::setlane(S.hfl, i, set_vec_sel(fl0, -1, sel));
+          can = true;
+        }
+      } else if (vec == 2) {  // Human::shot_it CH:399-408
+        const int32_t *w = d.weapon[sel];
+        if (st + w[0] < 0)
+          can = false;
+        else {
+          W::setlane(S.hst, i, (uint32_t)(st + w[0]));
+          dmg = d.cd_weapon[sel] > w[1] + md ? d.cd_weapon[sel] : w[1] + md;
+          eff = w[2], range = w[3];
+          can = true;
+        }
+      } else
+        return;
+      uint32_t fl;
+      const int sit = showit(S, lds, p, f, rr, cc, fl);
+      if (can && bullet_may_enter(sit, fl)) bullet_put(S, index, pos_pack(f, rr, cc), way, dmg, eff, range, (int)i + 1);
+      return;
+    }
+  }
+
+  // human_rnpc_bot G:1927-1940
+  static SF_DEV uint32_t human_rnpc_bot(Arena &S) {
+    if (S.frame % 50 <= 1) {
+      const uint32_t k = draw(S) % 8u;
+      return (uint32_t)("cvbnm,./"[k]);
+    } else if (draw(S) % 5u < 3u)
+      return 'x';
+    else if (draw(S) % 5u < 3u) {
+      const uint32_t k = draw(S) % 7u;
+      return (uint32_t)("12awsdp"[k]);
+    }
+    const uint32_t k = draw(S) % 8u;
+    return (uint32_t)("+ufghj[]"[k]);
+  }
+
+  // human_action G:965-1012.  S.hcmd holds this step's external commands on lanes < n_agents.
+  static SF_DEV void human_action(Arena &S, uint8_t *lds, const Params &p, int a) {
+    const uint64_t alive = W::ballot((S.hfl & HF_ALIVE) != 0u) & capmask(p.H);
+    // get_command G:929-937, slot order, for i != ind: remote keep theirs, rnpc draw, agents keep theirs, others '+'
+    {
+      const P ext = ((S.hfl & (HF_REMOTE | HF_CTRL)) != 0u) | (W::lane() == 0u);
+      S.hcmd = W::select(ext, S.hcmd, V((uint32_t)'+'));
+      uint64_t m = alive & ~1ull & W::ballot((S.hfl & (HF_RNPC | HF_REMOTE)) == HF_RNPC);
+      while (m) {
+        const uint32_t i = (uint32_t)W::ctz64(m);
+        m &= m - 1ull;
+        W::setlane(S.hcmd, i, human_rnpc_bot(S));
+      }
+    }
+    const uint32_t r = draw(S) & 1u;
+    uint64_t m = alive;
+    while (m) {
+      const uint32_t i = r ? (uint32_t)W::ctz64(m) : (uint32_t)(63 - W::clz64(m));
+      m &= ~(1ull << i);
+      // a human killed by obey() of an earlier one is impossible (hits land in hit_human), so `alive` is stable
+      obey(S, lds, p, a, W::readlane(S.hcmd, i), i);
+      teleport(S, lds, p, a, i);
+      claim_chest(S, lds, p, i);
+    }
+    S.hcmd = V((uint32_t)'+');
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // check_end G:1102-1229 (logic only)
+  static SF_DEV bool rivals_are_dead(const Arena &S, uint32_t my_team) {  // G:497-505
+    const V team = (S.hfl >> HF_TEAM_SH) & 255u;
+    return W::ballot(((S.hfl & HF_ALIVE) != 0u) & (team != 0u) & (team != my_team)) == 0ull;
+  }
+  static SF_DEV int check_end(const Arena &S, const Params &p) {
+    const uint32_t my_team = (uint32_t)h_team(W::readlane(S.hfl, 0u));
+    if (p.mode == SF_MODE_BATTLE && rivals_are_dead(S, my_team)) return SF_WON;
+    if ((int32_t)W::readlane(S.hhp, 0u) <= 0) return SF_DIED;
+    if (p.mode == SF_MODE_TIMER) {
+      if (S.frame - 1 >= p.timer_lim) return S.kills < p.level * 5 ? SF_TIME_LOST : SF_TIME_WON;
+      return SF_RUNNING;
+    }
+    if (p.level * 5 <= S.kills && p.mode == SF_MODE_SOLO) return SF_WON;
+    if (p.level * 10 <= S.tkills && rivals_are_dead(S, my_team) && p.mode == SF_MODE_SQUAD) return SF_WON;
+    return SF_RUNNING;
+  }
+
+  static SF_DEV void latch_results(const Arena &S, const Params &p, int a) {
+    // [kills, teams_kills, loot, damage, effect, Hp, frames, outcome] per agent
+    const P ag = W::ltu(W::lane(), (uint32_t)p.n_agents);
+    const V base = (V((uint32_t)a * (uint32_t)p.n_agents) + W::lane()) * 8u;
+    uint32_t *res = (uint32_t *)p.results;
+    W::gstore(res, base + 0u, S.hk, ag);
+    W::gstore(res, base + 1u, V((uint32_t)S.tkills), ag);
+    W::gstore(res, base + 2u, V((uint32_t)S.loot), ag);
+    W::gstore(res, base + 3u, S.hdm, ag);
+    W::gstore(res, base + 4u, S.hef, ag);
+    W::gstore(res, base + 5u, S.hhp, ag);
+    W::gstore(res, base + 6u, V((uint32_t)S.frame), ag);
+    W::gstore(res, base + 7u, V((uint32_t)S.outcome), ag);
+  }
+
+  // top of play()'s while(true): G:1444-1450
+  static SF_DEV void loop_top(Arena &S, uint8_t *lds, const Params &p, int a) {
+    if (S.frame % 30 <= 1) spawn_chest(S, lds, p);
+    if (S.frame % 40 <= 1) spawn_zombie_npc(S, lds, p);
+    if (S.frame % 50 <= 1) spawn_human_npc(S, lds, p);
+    const int out = check_end(S, p);
+    if (out != SF_RUNNING) {
+      S.done = 1, S.outcome = out;
+      latch_results(S, p, a);
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // setup() G:1231-1277 + load_data() G:1741-1925 for this arena, then the first loop top.
+  static SF_DEV void reset(Arena &S, uint8_t *lds, const Params &p, int a, uint64_t tb, uint64_t serial) {
+    S.frame = S.kills = S.tkills = S.loot = S.chests = S.steps = 0;
+    S.done = 0, S.outcome = SF_RUNNING;
+    S.draws = 0u;
+    S.tb_lo = (uint32_t)tb, S.tb_hi = (uint32_t)(tb >> 32), S.sr_lo = (uint32_t)serial, S.sr_hi = (uint32_t)(serial >> 32);
+    S.hpos = V(POS_NONE), S.hfl = V(0u), S.hhp = V(0u), S.hst = V(0u), S.hmd = V(0u), S.hk = V(0u), S.hdm = V(0u);
+    S.hef = V(0u), S.hc01 = V(0u), S.hc23 = V(0u), S.ht01 = V(0u), S.ht23 = V(0u), S.hbpk = V(0u);
+    S.hcmd = V((uint32_t)'+');
+    S.zpos = V(0u), S.zhp = V(0u), S.zmd = V(0u);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) S.ba[j] = V(0u), S.bd[j] = V(0u), S.bb[j] = V(0u), S.bc[j] = V(0u);
+    S.ppos = W::gload(p.map_exits, W::lane(), W::ltu(W::lane(), (uint32_t)p.P));
+    W::copy_g2l(lds, p.map_flags, (uint32_t)p.cells_pad);
+    S.dirty = 1u;
+    srand_(S, tb, serial);
+    if (p.mode == SF_MODE_BATTLE) {  // G:1846-1859
+      for (int i = 0; i < p.n_agents; ++i)
+        human_make(S, p, (uint32_t)i, 0, POS_NONE, 1, p.tab->teams[i], HF_CTRL | (i ? HF_REMOTE : 0u));
+      // not yet on the map: clear the designation until placed
+      S.hfl = S.hfl & ~HF_OCC;
+      for (int i = 0; i < p.n_agents; ++i) {
+        const uint32_t way = draw(S) % 4u + 1u;
+        for (int guard = 0; guard < (1 << 20); ++guard) {  // `while(true)` with an exit every wave reaches
+          int f = (int)(draw(S) % (uint32_t)p.F), r = (int)(draw(S) % (uint32_t)p.N), c = (int)(draw(S) % (uint32_t)p.M);
+          uint32_t fl;
+          if (showit(S, lds, p, f, r, c, fl) == SH_EMPTY) {
+            W::setlane(S.hpos, (uint32_t)i, pos_pack(f, r, c));
+            W::setlane(S.hfl, (uint32_t)i, ((W::readlane(S.hfl, (uint32_t)i) & ~HF_WAY_MASK) | way) | HF_OCC);
+            break;
+          }
+        }
+      }
+    } else if (p.mode == SF_MODE_SQUAD) {  // G:1861-1903
+      human_make(S, p, 0u, 0, pos_pack(0, 3, 1), 1, 1, HF_CTRL);
+      for (int i = 1; i < 5; ++i)
+        human_make(S, p, (uint32_t)i, 1, pos_pack(0, 1, i + 1), 1, 1, i < p.n_agents ? HF_CTRL : 0u);
+      for (int i = 5; i < 10; ++i)
+        human_make(S, p, (uint32_t)i, 1, pos_pack(p.squad_floor, 1, i + 1), 1, 2, i < p.n_agents ? HF_CTRL : 0u);
+    } else {  // Solo / Timer G:1905-1920
+      human_make(S, p, 0u, 0, pos_pack(0, 1, 1), 1, 1, HF_CTRL);
+    }
+    ++S.frame;  // G:1441
+    loop_top(S, lds, p, a);
+  }
+
+  // One iteration of the loop body G:1452-1471 followed by the next loop top.
+  static SF_DEV void step(Arena &S, uint8_t *lds, const Params &p, int a) {
+    S.ended = 0;
+    if (S.done) return;
+    zombie_action(S, lds, p);
+    portal_damage(S, lds, p);
+    update_tmp(S, lds, p, a);
+    hits(S);
+    ++S.frame;  // updmap G:489-495 clears render-only bits
+    update_bull(S, lds, p);
+    human_action(S, lds, p, a);
+    update_tmp(S, lds, p, a);
+    hits(S);
+    ++S.frame;
+    update_bull(S, lds, p);
+    ++S.steps;
+    loop_top(S, lds, p, a);
+    if (S.done) {
+      S.ended = 1;
+      ++S.episodes;
+      if (p.auto_reset) {
+        const uint64_t tb = (((uint64_t)S.tb_hi << 32) | S.tb_lo) + (uint64_t)p.A;
+        const uint64_t sr = ((uint64_t)S.sr_hi << 32) | S.sr_lo;
+        const int32_t ep = S.episodes;
+        reset(S, lds, p, a, tb, sr);
+        S.episodes = ep;
+        S.ended = 1;
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // HBM <-> registers / LDS
+  static SF_DEV void load(Arena &S, uint8_t *lds, const Params &p, int a) {
+    const V ln = W::lane();
+    const size_t AH = (size_t)p.A * (size_t)p.H, AZ = (size_t)p.A * (size_t)p.Z, AB = (size_t)p.A * (size_t)p.B;
+    {
+      const P in = W::ltu(ln, (uint32_t)p.H);
+      const uint32_t *h = p.hum + (size_t)a * (size_t)p.H;
+      S.hpos = W::gload(h + HW_POS * AH, ln, in), S.hfl = W::gload(h + HW_FLAGS * AH, ln, in);
+      S.hhp = W::gload(h + HW_HP * AH, ln, in), S.hst = W::gload(h + HW_STAMINA * AH, ln, in);
+      S.hmd = W::gload(h + HW_MINDAMAGE * AH, ln, in), S.hk = W::gload(h + HW_KILLS * AH, ln, in);
+      S.hdm = W::gload(h + HW_DAMAGE * AH, ln, in), S.hef = W::gload(h + HW_EFFECT * AH, ln, in);
+      S.hc01 = W::gload(h + HW_CONS01 * AH, ln, in), S.hc23 = W::gload(h + HW_CONS23 * AH, ln, in);
+      S.ht01 = W::gload(h + HW_THR01 * AH, ln, in), S.ht23 = W::gload(h + HW_THR23 * AH, ln, in);
+      S.hbpk = W::gload(h + HW_BPK * AH, ln, in);
+      S.hcmd = V((uint32_t)'+');
+    }
+    {
+      const P in = W::ltu(ln, (uint32_t)p.Z);
+      const uint32_t *z = p.zom + (size_t)a * (size_t)p.Z;
+      S.zpos = W::gload(z + ZW_POS * AZ, ln, in), S.zhp = W::gload(z + ZW_HP * AZ, ln, in);
+      S.zmd = W::gload(z + ZW_MINDAMAGE * AZ, ln, in);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const V sl = ln + (uint32_t)(64 * j);
+      const P in = W::ltu(sl, (uint32_t)p.B);
+      const uint32_t *b = p.bul + (size_t)a * (size_t)p.B;
+      S.ba[j] = W::gload(b + BW_A * AB, sl, in), S.bd[j] = W::gload(b + BW_DAMAGE * AB, sl, in);
+      S.bb[j] = W::gload(b + BW_B * AB, sl, in), S.bc[j] = W::gload(b + BW_C * AB, sl, in);
+    }
+    S.ppos = W::gload(p.por + (size_t)a * (size_t)p.P, ln, W::ltu(ln, (uint32_t)p.P));
+    {
+      // one dword per tap: random[i] | us[i] << 20 | seed[i] << 24  (RN:31; us/seed are decimal digits + 1)
+      const V rw = W::gload(p.rng + (size_t)a * RNG_WORDS, ln, W::ltu(ln, 18u));
+      S.rv = rw & 0xfffffu, S.rus = (rw >> 20) & 15u, S.rseed = (rw >> 24) & 15u;
+    }
+    const V sc = W::gload((const uint32_t *)p.scal + (size_t)a * SC_WORDS, ln, W::ltu(ln, (uint32_t)SC_WORDS));
+    S.frame = (int32_t)W::readlane(sc, SC_FRAME), S.kills = (int32_t)W::readlane(sc, SC_KILLS);
+    S.tkills = (int32_t)W::readlane(sc, SC_TKILLS), S.loot = (int32_t)W::readlane(sc, SC_LOOT);
+    S.chests = (int32_t)W::readlane(sc, SC_CHESTS), S.jomle = W::readlane(sc, SC_JOMLE);
+    S.steps = (int32_t)W::readlane(sc, SC_STEPS), S.episodes = (int32_t)W::readlane(sc, SC_EPISODES);
+    S.done = (int32_t)W::readlane(sc, SC_DONE), S.outcome = (int32_t)W::readlane(sc, SC_OUTCOME);
+    S.ended = (int32_t)W::readlane(sc, SC_ENDED);
+    S.tb_lo = W::readlane(sc, SC_TB_LO), S.tb_hi = W::readlane(sc, SC_TB_HI);
+    S.sr_lo = W::readlane(sc, SC_SR_LO), S.sr_hi = W::readlane(sc, SC_SR_HI);
+    S.draws = W::readlane(sc, SC_DRAWS);
+    W::copy_g2l(lds, p.flags + (size_t)a * (size_t)p.cells_pad, (uint32_t)p.cells_pad);
+    S.dirty = 0u;
+  }
+
+  static SF_DEV void store(const Arena &S, const uint8_t *lds, const Params &p, int a) {
+    const V ln = W::lane();
+    const size_t AH = (size_t)p.A * (size_t)p.H, AZ = (size_t)p.A * (size_t)p.Z, AB = (size_t)p.A * (size_t)p.B;
+    {
+      const P in = W::ltu(ln, (uint32_t)p.H);
+      uint32_t *h = p.hum + (size_t)a * (size_t)p.H;
+      W::gstore(h + HW_POS * AH, ln, S.hpos, in), W::gstore(h + HW_FLAGS * AH, ln, S.hfl, in);
+      W::gstore(h + HW_HP * AH, ln, S.hhp, in), W::gstore(h + HW_STAMINA * AH, ln, S.hst, in);
+      W::gstore(h + HW_MINDAMAGE * AH, ln, S.hmd, in), W::gstore(h + HW_KILLS * AH, ln, S.hk, in);
+      W::gstore(h + HW_DAMAGE * AH, ln, S.hdm, in), W::gstore(h + HW_EFFECT * AH, ln, S.hef, in);
+      W::gstore(h + HW_CONS01 * AH, ln, S.hc01, in), W::gstore(h + HW_CONS23 * AH, ln, S.hc23, in);
+      W::gstore(h + HW_THR01 * AH, ln, S.ht01, in), W::gstore(h + HW_THR23 * AH, ln, S.ht23, in);
+      W::gstore(h + HW_BPK * AH, ln, S.hbpk, in);
+    }
+    {
+      const P in = W::ltu(ln, (uint32_t)p.Z);
+      uint32_t *z = p.zom + (size_t)a * (size_t)p.Z;
+      W::gstore(z + ZW_POS * AZ, ln, S.zpos, in), W::gstore(z + ZW_HP * AZ, ln, S.zhp, in);
+      W::gstore(z + ZW_MINDAMAGE * AZ, ln, S.zmd, in);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const V sl = ln + (uint32_t)(64 * j);
+      const P in = W::ltu(sl, (uint32_t)p.B);
+      uint32_t *b = p.bul + (size_t)a * (size_t)p.B;
+      W::gstore(b + BW_A * AB, sl, S.ba[j], in), W::gstore(b + BW_DAMAGE * AB, sl, S.bd[j], in);
+      W::gstore(b + BW_B * AB, sl, S.bb[j], in), W::gstore(b + BW_C * AB, sl, S.bc[j], in);
+    }
+    W::gstore(p.por + (size_t)a * (size_t)p.P, ln, S.ppos, W::ltu(ln, (uint32_t)p.P));
+    W::gstore(p.rng + (size_t)a * RNG_WORDS, ln, S.rv | (S.rus << 20) | (S.rseed << 24), W::ltu(ln, 18u));
+    V sc = V(0u);
+    W::setlane(sc, SC_FRAME, (uint32_t)S.frame), W::setlane(sc, SC_KILLS, (uint32_t)S.kills);
+    W::setlane(sc, SC_TKILLS, (uint32_t)S.tkills), W::setlane(sc, SC_LOOT, (uint32_t)S.loot);
+    W::setlane(sc, SC_CHESTS, (uint32_t)S.chests), W::setlane(sc, SC_JOMLE, S.jomle);
+    W::setlane(sc, SC_STEPS, (uint32_t)S.steps), W::setlane(sc, SC_EPISODES, (uint32_t)S.episodes);
+    W::setlane(sc, SC_DONE, (uint32_t)S.done), W::setlane(sc, SC_OUTCOME, (uint32_t)S.outcome);
+    W::setlane(sc, SC_ENDED, (uint32_t)S.ended);
+    W::setlane(sc, SC_TB_LO, S.tb_lo), W::setlane(sc, SC_TB_HI, S.tb_hi);
+    W::setlane(sc, SC_SR_LO, S.sr_lo), W::setlane(sc, SC_SR_HI, S.sr_hi);
+    W::setlane(sc, SC_DRAWS, S.draws);
+    W::gstore((uint32_t *)p.scal + (size_t)a * SC_WORDS, ln, sc, W::ltu(ln, (uint32_t)SC_WORDS));
+    if (S.dirty) W::copy_l2g(p.flags + (size_t)a * (size_t)p.cells_pad, lds, (uint32_t)p.cells_pad);
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // kernel bodies
+  static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial) {
+    Arena S;
+    S.episodes = 0, S.ended = 0;
+    reset(S, lds, p, a, tb[a], serial[a]);
+    store(S, lds, p, a);
+  }
+
+  // cmds: [k][A][n_agents]
+  static SF_DEV void step_body(uint8_t *lds, const Params &p, int a, const uint8_t *cmds, int k) {
+    Arena S;
+    load(S, lds, p, a);
+    const P ag = W::ltu(W::lane(), (uint32_t)p.n_agents);
+    for (int s = 0; s < k; ++s) {
+      const uint8_t *c = cmds + ((size_t)s * (size_t)p.A + (size_t)a) * (size_t)p.n_agents;
+      S.hcmd = W::select(ag, W::gload_u8(c, W::lane(), ag), V((uint32_t)'+'));
+      step(S, lds, p, a);
+    }
+    store(S, lds, p, a);
+  }
+};
+
+}  // namespace sf

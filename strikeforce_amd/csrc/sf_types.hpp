@@ -1,0 +1,104 @@
+// sf_types.hpp — HBM data layout of the batched arena state, shared by the device core and the host API.
+//
+// Everything an arena owns is struct-of-arrays, arena-major / slot-minor, so that the wavefront that
+// owns arena `a` loads field f of all its entities with one coalesced instruction
+// (address = base_f + (a * CAP + lane) * 4).  See DESIGN.md §Layout.
+#pragma once
+#include <stdint.h>
+
+// SF_HD: usable from host code and from gfx950 device code (hipcc defines the qualifiers; the
+// test-only wave emulator under tests/emu is built with g++ and sees none).
+#if defined(__HIPCC__)
+#define SF_HD __host__ __device__
+#else
+#define SF_HD
+#endif
+
+namespace sf {
+
+// ---- packed position: f << 20 | r << 10 | c (coordinates < 1024, random.hpp:62) ----------------------
+constexpr uint32_t POS_MASK = 0x3FFFFFu;
+constexpr uint32_t POS_NONE = 0x3FFFFFu;
+SF_HD inline uint32_t pos_pack(int f, int r, int c) {
+  return ((uint32_t)f << 20) | ((uint32_t)r << 10) | (uint32_t)c;
+}
+SF_HD inline int pos_f(uint32_t p) { return (int)((p >> 20) & 3u); }
+SF_HD inline int pos_r(uint32_t p) { return (int)((p >> 10) & 1023u); }
+SF_HD inline int pos_c(uint32_t p) { return (int)(p & 1023u); }
+
+// ---- human record: 13 dwords -----------------------------------------------------------------------
+enum { HW_POS = 0, HW_FLAGS, HW_HP, HW_STAMINA, HW_MINDAMAGE, HW_KILLS, HW_DAMAGE, HW_EFFECT, HW_CONS01, HW_CONS23,
+       HW_THR01, HW_THR23, HW_BPK, HW_WORDS };
+// HW_FLAGS bit layout
+constexpr uint32_t HF_WAY_MASK = 7u;          // way 1..4 (gameplay.hpp:43)
+constexpr int HF_TEAM_SH = 3;                 // 8 bits
+constexpr uint32_t HF_ALIVE = 1u << 11;       // mh[i]
+constexpr uint32_t HF_REMOTE = 1u << 12;      // remote[i]
+constexpr uint32_t HF_RNPC = 1u << 13;        // Human::rnpc
+constexpr uint32_t HF_PROF = 1u << 14;        // 0 player profile, 1 npc profile
+constexpr uint32_t HF_CTRL = 1u << 15;        // active_agent: commanded through sf_step
+constexpr int HF_VEC_SH = 16;                 // 2 bits: backpack.vec + 1
+constexpr int HF_IND_SH = 18;                 // 4 bits: backpack.ind + 1
+constexpr uint32_t HF_OCC = 1u << 22;         // the cell's s[0] designates this human (alive, or dead `ind`)
+// HW_BPK: blocks | portals << 8 | (portal_ind + 1) << 16
+
+// ---- zombie record: 3 dwords -----------------------------------------------------------------------
+enum { ZW_POS = 0, ZW_HP, ZW_MINDAMAGE, ZW_WORDS };
+constexpr uint32_t ZF_SUPER = 1u << 30, ZF_ALIVE = 1u << 31;
+
+// ---- bullet record: 4 dwords -----------------------------------------------------------------------
+enum { BW_A = 0, BW_DAMAGE, BW_B, BW_C, BW_WORDS };
+// BW_A: pos | (way-1) << 22 | alive << 24 | ref << 25 ; BW_B: (uint16)effect | owner << 16 ; BW_C: range | traveled << 16
+constexpr int BA_WAY_SH = 22;
+constexpr uint32_t BA_ALIVE = 1u << 24, BA_REF = 1u << 25;
+
+// ---- portal record: 1 dword: pos | active << 31 -----------------------------------------------------
+constexpr uint32_t PF_ACTIVE = 1u << 31;
+
+// ---- per-arena scalar block: 24 dwords ----------------------------------------------------------------
+enum { SC_FRAME = 0, SC_KILLS, SC_TKILLS, SC_LOOT, SC_CHESTS, SC_JOMLE, SC_STEPS, SC_EPISODES, SC_DONE, SC_OUTCOME,
+       SC_ENDED, SC_TB_LO, SC_TB_HI, SC_SR_LO, SC_SR_HI, SC_DRAWS, SC_WORDS = 24 };
+constexpr int RNG_WORDS = 18;
+
+// ---- derived per-profile tables (Human::build, Character.hpp:650-709) ---------------------------------
+struct Derived {
+  int32_t hp, mindamage, stamina, mindamage_def;
+  int32_t cd_punch;          // compute_damage(mindamage_def, 1)      Character.hpp:393
+  int32_t blocks, portals;
+  int32_t cons[4], thr_cnt[4];
+  int32_t thr[4][4];         // stamina, damage, effect, range
+  int32_t weapon[8][4];
+  int32_t weapon_lvl[8];
+  int32_t cd_weapon[8];      // compute_damage(w.damage, w.range)     Character.hpp:404
+};
+
+struct Tables {
+  Derived der[2];
+  int32_t cons_items[4][3];  // stamina, Hp, effect
+  int32_t teams[16];         // BATTLE mode team of agent i
+};
+
+// ---- everything a kernel needs -----------------------------------------------------------------------
+struct Params {
+  int32_t A, F, N, M, cells, cells_pad;
+  int32_t H, Z, B, P, C;
+  int32_t mode, level, n_agents, auto_reset, timer_lim, squad_floor;
+  const Tables *tab;
+  uint32_t *hum;   // [HW_WORDS][A][H]
+  uint32_t *zom;   // [ZW_WORDS][A][Z]
+  uint32_t *bul;   // [BW_WORDS][A][B]
+  uint32_t *por;   // [A][P]
+  uint32_t *rng;   // [A][RNG_WORDS]
+  int32_t *scal;   // [A][SC_WORDS]
+  int32_t *results;// [A][n_agents][8]
+  uint8_t *flags;  // [A][cells_pad]
+  int32_t *aux_dmg;   // [A][cells]   valid only where SF_CELL_TEMP
+  int16_t *aux_pidx;  // [A][cells]   valid only where SF_CELL_TEMP|SF_CELL_PIN_UP
+  const uint8_t *map_flags;  // [cells_pad]
+  const int16_t *map_pidx;   // [cells]
+  const uint32_t *map_exits; // [P]
+};
+
+inline int nb_for(int B) { return (B + 63) / 64; }
+
+}  // namespace sf

@@ -1,0 +1,91 @@
+// wave_gfx950.hpp — the CDNA4 (gfx950) wavefront backend of sf_core.hpp.
+//
+// One workgroup = one 64-lane wavefront = one arena.  Per-lane values are plain registers; cross-lane
+// traffic uses v_readlane / DPP / s_ballot, never LDS.  Wave-uniform values produced here (ballots,
+// readlane, readfirstlane) are SGPRs, so the slot-ordered loops of the core compile to scalar control
+// flow with the vector unit doing the per-entity predicated updates.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SF_DEV __device__ __forceinline__
+
+namespace sf {
+
+struct WaveGfx950 {
+  using V = uint32_t;
+  using P = bool;
+
+  static SF_DEV V lane() { return threadIdx.x; }
+  static SF_DEV uint64_t ballot(P p) { return __builtin_amdgcn_ballot_w64(p); }
+  static SF_DEV int ctz64(uint64_t m) { return __builtin_ctzll(m); }
+  static SF_DEV int clz64(uint64_t m) { return __builtin_clzll(m); }
+  static SF_DEV uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+  static SF_DEV uint32_t readlane(const V &v, uint32_t idx) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uni(idx));
+  }
+  static SF_DEV void setlane(V &v, uint32_t idx, uint32_t val) {
+    v = (threadIdx.x == uni(idx)) ? val : v;  // v_cmp + v_cndmask (this clang has no writelane builtin)
+  }
+  static SF_DEV V select(P p, V a, V b) { return p ? a : b; }
+  static SF_DEV V sar31(V v) { return (uint32_t)((int32_t)v >> 31); }
+  static SF_DEV P le0(V v) { return (int32_t)v <= 0; }
+  static SF_DEV P ltu(V a, V b) { return a < b; }
+  static SF_DEV P frombits(uint64_t m) { return (m >> threadIdx.x) & 1ull; }
+
+  // sum over lanes 0..17 of a value that is zero on lanes >= 18: two DPP row reductions + two readlanes
+  static SF_DEV uint32_t sum18(V v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);  // row_mirror
+    return (uint32_t)(__builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16));
+  }
+  // lane i <- lane i + 1 (wave_shl:1, a gfx9 DPP control); lane 63 reads 0
+  static SF_DEV V shl1(V v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+
+  // LDS flag plane
+  static SF_DEV V lds_u8(const uint8_t *lds, V idx, P pred) { return pred ? (uint32_t)lds[idx] : 0u; }
+  static SF_DEV uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return uni((uint32_t)lds[idx]); }
+  static SF_DEV void ulds_store_u8(uint8_t *lds, uint32_t idx, uint32_t val) {
+    lds[idx] = (uint8_t)val;  // every lane writes the same byte: no divergence, one LDS pass
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // wave-uniform access to the sparse per-cell side tables in HBM (rare path).  Relaxed atomics keep
+  // these on the vector memory path, which is coherent with this wave's own earlier stores.
+  static SF_DEV int32_t uload_i32(const int32_t *p) {
+    return (int32_t)uni((uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+  }
+  static SF_DEV void ustore_i32(int32_t *p, int32_t v) {
+    if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  static SF_DEV int32_t uload_i16(const int16_t *p) {
+    return (int32_t)(int16_t)uni((uint32_t)(uint16_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+  }
+  static SF_DEV void ustore_i16(int16_t *p, int16_t v) {
+    if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+
+  // per-lane HBM access (struct-of-arrays: consecutive lanes hit consecutive dwords)
+  static SF_DEV V gload(const uint32_t *base, V idx, P pred) { return pred ? base[idx] : 0u; }
+  static SF_DEV V gload_u8(const uint8_t *base, V idx, P pred) { return pred ? (uint32_t)base[idx] : 0u; }
+  static SF_DEV void gstore(uint32_t *base, V idx, V val, P pred) {
+    if (pred) base[idx] = val;
+  }
+
+  // flag plane <-> LDS, 16 B per lane per pass (nbytes is a multiple of 16)
+  static SF_DEV void copy_g2l(uint8_t *lds, const uint8_t *g, uint32_t nbytes) {
+    for (uint32_t off = threadIdx.x * 16u; off < nbytes; off += 64u * 16u)
+      *reinterpret_cast<uint4 *>(lds + off) = *reinterpret_cast<const uint4 *>(g + off);
+    __builtin_amdgcn_wave_barrier();
+  }
+  static SF_DEV void copy_l2g(uint8_t *g, const uint8_t *lds, uint32_t nbytes) {
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t off = threadIdx.x * 16u; off < nbytes; off += 64u * 16u)
+      *reinterpret_cast<uint4 *>(g + off) = *reinterpret_cast<const uint4 *>(lds + off);
+  }
+};
+
+}  // namespace sf

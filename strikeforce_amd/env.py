@@ -1,0 +1,159 @@
+"""Host-side mirror of the reference's environment surface over the C-ABI (include/strikeforce.h).
+
+``ArenaBatch`` is plumbing only: it loads libstrikeforce_amd.so (hand-written gfx950 kernels) and moves
+pointers.  There is no CPU path — if the library is missing or no MI355X is visible it raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstrikeforce_amd.so")
+_LIB = None
+
+
+class StrikeForceError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load the HIP library and declare its signatures.  Raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise StrikeForceError(
+                "libstrikeforce_amd.so is missing: run `python -m strikeforce_amd.build` (hipcc, gfx950). "
+                "strikeforce_amd has no CPU path.")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.sf_create.argtypes = [C.POINTER(abi.Config), C.POINTER(vp)]
+        L.sf_create.restype = C.c_int
+        abi.bind(L, "sf_")
+        L.sf_destroy.restype = C.c_int
+        L.sf_step_device.argtypes = [vp, vp, C.c_int32]
+        L.sf_observe_device.argtypes = [vp, vp]
+        L.sf_results_device.argtypes = [vp, vp]
+        L.sf_set_stream.argtypes = [vp, vp]
+        L.sf_synchronize.argtypes = [vp]
+        L.sf_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.sf_config_defaults.argtypes = [C.POINTER(abi.Config)]
+        L.sf_config_defaults.restype = None
+        for n in ("sf_step_device", "sf_observe_device", "sf_results_device", "sf_set_stream", "sf_synchronize",
+                  "sf_kernel_time", "sf_abi_version"):
+            getattr(L, n).restype = C.c_int
+        L.sf_last_error.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+# every symbol include/strikeforce.h declares
+EXPORTS = ["sf_create", "sf_destroy", "sf_config_defaults", "sf_reset", "sf_step", "sf_step_device", "sf_observe",
+           "sf_observe_device", "sf_results", "sf_results_device", "sf_done", "sf_state_digest", "sf_dump_arena",
+           "sf_set_stream", "sf_synchronize", "sf_kernel_time", "sf_last_error", "sf_abi_version"]
+
+
+class ArenaBatch:
+    """A batch of independent arenas on one GPU.
+
+    Mirrors the reference loop (gameplay.hpp:1428-1505): ``reset`` = setup()+load_data() and the first
+    loop top; ``step`` = one iteration of play()'s while(true) for every arena, commands are the
+    reference's command chars; ``observe`` = gameplay::bot()'s 32x31x31 encoding
+    (bots/bot-0.5/Custom.hpp:137-159); ``done`` = check_end().
+    """
+
+    def __init__(self, workload):
+        self.w = workload
+        self.cfg = workload.cfg
+        self.L = load_library()
+        self.h = C.c_void_p()
+        rc = self.L.sf_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise StrikeForceError("sf_create failed (%d): %s" % (rc, self.L.sf_last_error().decode()))
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise StrikeForceError("%s failed (%d): %s" % (what, rc, self.L.sf_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        self._ck(self.L.sf_set_stream(self.h, C.c_void_p(hip_stream)), "sf_set_stream")
+
+    def synchronize(self):
+        self._ck(self.L.sf_synchronize(self.h), "sf_synchronize")
+
+    def reset(self, tb, serial):
+        self._ck(self.L.sf_reset(self.h, tb, serial), "sf_reset")
+
+    def step(self, cmd):
+        cmd = np.ascontiguousarray(cmd, dtype=np.uint8)
+        if cmd.size != self.cfg.arenas * self.cfg.n_agents:
+            raise ValueError("cmd must hold arenas * n_agents command chars")
+        self._ck(self.L.sf_step(self.h, cmd.ctypes.data_as(C.c_char_p)), "sf_step")
+
+    def step_device(self, d_cmd_ptr, k):
+        """k loop iterations in one launch; d_cmd_ptr: device address of uint8 [k][arenas][n_agents]."""
+        self._ck(self.L.sf_step_device(self.h, C.c_void_p(d_cmd_ptr), k), "sf_step_device")
+
+    def observe(self):
+        out = np.empty((self.cfg.arenas, self.cfg.n_agents, abi.OBS_CHANNELS, abi.OBS_WINDOW, abi.OBS_WINDOW),
+                       dtype=np.float32)
+        self._ck(self.L.sf_observe(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "sf_observe")
+        return out
+
+    def observe_device(self, d_out_ptr):
+        self._ck(self.L.sf_observe_device(self.h, C.c_void_p(d_out_ptr)), "sf_observe_device")
+
+    def results(self):
+        out = np.zeros((self.cfg.arenas, self.cfg.n_agents, 8), dtype=np.int32)
+        self._ck(self.L.sf_results(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))), "sf_results")
+        return out
+
+    def results_device(self, d_out_ptr):
+        self._ck(self.L.sf_results_device(self.h, C.c_void_p(d_out_ptr)), "sf_results_device")
+
+    def done(self):
+        out = np.zeros(self.cfg.arenas, dtype=np.uint8)
+        self._ck(self.L.sf_done(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))), "sf_done")
+        return out
+
+    def digest(self):
+        out = np.zeros(self.cfg.arenas, dtype=np.uint64)
+        self._ck(self.L.sf_state_digest(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))), "sf_state_digest")
+        return out
+
+    def dump_raw(self, arena):
+        cfg = self.cfg
+        cells = cfg.floors * cfg.rows * cfg.cols
+        hdr = abi.ArenaHdr()
+        hs = (abi.HumanRec * cfg.cap_humans)()
+        zs = (abi.ZombieRec * cfg.cap_zombies)()
+        bs = (abi.BulletRec * cfg.cap_bullets)()
+        ps = (abi.PortalRec * cfg.cap_portals)()
+        flags = np.zeros(cells, dtype=np.uint8)
+        dmg = np.zeros(cells, dtype=np.int32)
+        pidx = np.zeros(cells, dtype=np.int32)
+        self._ck(self.L.sf_dump_arena(self.h, arena, C.byref(hdr), hs, zs, bs, ps,
+                                      flags.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                      dmg.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      pidx.ctypes.data_as(C.POINTER(C.c_int32))), "sf_dump_arena")
+        return hdr, list(hs), list(zs), list(bs), list(ps), flags, dmg, pidx
+
+    def kernel_time(self, enable=True):
+        """(ms, launches) of the step kernels since the last call, from HIP events on the launch stream."""
+        ms, n = C.c_float(0), C.c_int32(0)
+        self._ck(self.L.sf_kernel_time(self.h, 1 if enable else 0, C.byref(ms), C.byref(n)), "sf_kernel_time")
+        return ms.value, n.value

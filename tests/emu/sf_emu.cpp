@@ -1,0 +1,144 @@
+// sf_emu.cpp — TEST INFRASTRUCTURE: the device core (strikeforce_amd/csrc/sf_core.hpp) and the host API
+// (sf_host.hpp) compiled for the CPU against a 64-lane wave emulator.  Exports the C-ABI of
+// include/strikeforce.h with an `sfe_` prefix.  Loaded only by tests/ (CPU parity of the kernel logic
+// against the oracle, ASan/UBSan runs); never part of, or a fallback for, the product library.
+#include <stdlib.h>
+
+#include <vector>
+
+#include "wave_emu.hpp"
+// clang-format off
+#include "../../strikeforce_amd/csrc/sf_core.hpp"
+#include "../../strikeforce_amd/csrc/sf_obs.hpp"
+#include "../../strikeforce_amd/csrc/sf_host.hpp"
+// clang-format on
+
+namespace sf {
+
+template <int NB>
+static void run_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
+  std::vector<uint8_t> lds((size_t)p.cells_pad);
+  for (int a = 0; a < p.A; ++a) Core<WaveEmu, NB>::reset_body(lds.data(), p, a, tb, serial);
+}
+template <int NB>
+static void run_step(const Params &p, const uint8_t *cmds, int k) {
+  std::vector<uint8_t> lds((size_t)p.cells_pad);
+  for (int a = 0; a < p.A; ++a) Core<WaveEmu, NB>::step_body(lds.data(), p, a, cmds, k);
+}
+
+static void run_observe(const Params &p, float *out) {
+  const int W2 = SF_OBS_WINDOW * SF_OBS_WINDOW;
+  std::vector<uint32_t> occ(W2);
+  for (int a = 0; a < p.A; ++a)
+    for (int g = 0; g < p.n_agents; ++g) {
+      float *o = out + ((size_t)a * p.n_agents + g) * SF_OBS_FLOATS;
+      ObsView v(p, a);
+      const uint32_t hf = v.hum(HW_FLAGS, g);
+      if ((hf & (HF_ALIVE | HF_CTRL)) != (HF_ALIVE | HF_CTRL)) {
+        for (int i = 0; i < SF_OBS_FLOATS; ++i) o[i] = 0.f;
+        continue;
+      }
+      const uint32_t center = v.hum(HW_POS, g);
+      const int pteam = (int)((hf >> HF_TEAM_SH) & 255u);
+      for (int w = 0; w < W2; ++w) occ[w] = 0;
+      for (int h = 0; h < p.H; ++h)
+        if (v.hum(HW_FLAGS, h) & HF_OCC) {
+          int s = obs_window_slot(v.hum(HW_POS, h), center);
+          if (s >= 0) occ[s] |= (uint32_t)(h + 1);
+        }
+      for (int z = 0; z < p.Z; ++z)
+        if (v.zom(ZW_POS, z) & ZF_ALIVE) {
+          int s = obs_window_slot(v.zom(ZW_POS, z) & POS_MASK, center);
+          if (s >= 0) occ[s] |= (uint32_t)(z + 1) << 8;
+        }
+      for (int b = 0; b < p.B; ++b)
+        if (v.bul(BW_A, b) & BA_REF) {
+          int s = obs_window_slot(v.bul(BW_A, b) & POS_MASK, center);
+          if (s >= 0) occ[s] |= (uint32_t)(b + 1) << 16;
+        }
+      for (int w = 0; w < W2; ++w) {
+        const int i = pos_r(center) - SF_OBS_WINDOW / 2 + w / SF_OBS_WINDOW;
+        const int j = pos_c(center) - SF_OBS_WINDOW / 2 + w % SF_OBS_WINDOW;
+        uint32_t fl = 0;
+        int32_t cdmg = 0;
+        if (i >= 0 && j >= 0 && i < p.N && j < p.M) {
+          const size_t ci = (size_t)(pos_f(center) * p.N + i) * p.M + j;
+          fl = p.flags[(size_t)a * p.cells_pad + ci];
+          if (fl & SF_CELL_TEMP) cdmg = p.aux_dmg[(size_t)a * p.cells + ci];
+        }
+        for (int k = 0; k < SF_OBS_CHANNELS; ++k) o[k * W2 + w] = obs_map(obs_feature(v, k, fl, cdmg, occ[w], pteam));
+      }
+    }
+}
+
+struct CpuRT {
+  int init(int) { return SF_OK; }
+  void shutdown() {}
+  size_t max_lds() const { return 160 * 1024; }
+  void *alloc(size_t n) { return calloc(n ? n : 1, 1); }
+  void free(void *p) { ::free(p); }
+  void h2d(void *d, const void *s, size_t n) { memcpy(d, s, n); }
+  void d2h(void *d, const void *s, size_t n) { memcpy(d, s, n); }
+  void d2d(void *d, const void *s, size_t n) { memcpy(d, s, n); }
+  void zero(void *d, size_t n) { memset(d, 0, n); }
+  int sync() { return SF_OK; }
+  int launch_reset(const Params &p, int NB, const uint64_t *tb, const uint64_t *serial) {
+    switch (NB) {
+      case 1: run_reset<1>(p, tb, serial); break;
+      case 2: run_reset<2>(p, tb, serial); break;
+      case 3: run_reset<3>(p, tb, serial); break;
+      default: run_reset<4>(p, tb, serial); break;
+    }
+    return SF_OK;
+  }
+  int launch_step(const Params &p, int NB, const uint8_t *cmds, int k) {
+    switch (NB) {
+      case 1: run_step<1>(p, cmds, k); break;
+      case 2: run_step<2>(p, cmds, k); break;
+      case 3: run_step<3>(p, cmds, k); break;
+      default: run_step<4>(p, cmds, k); break;
+    }
+    return SF_OK;
+  }
+  int launch_observe(const Params &p, int, float *out) {
+    run_observe(p, out);
+    return SF_OK;
+  }
+};
+
+}  // namespace sf
+
+struct sfe_env {
+  sf::Env<sf::CpuRT> e;
+};
+
+extern "C" {
+sfe_env *sfe_create(const sf_config *cfg) {
+  sfe_env *env = new sfe_env();
+  if (env->e.create(cfg) != SF_OK) {
+    env->e.destroy();
+    delete env;
+    return nullptr;
+  }
+  return env;
+}
+int sfe_destroy(sfe_env *env) {
+  if (env) {
+    env->e.destroy();
+    delete env;
+  }
+  return SF_OK;
+}
+int sfe_reset(sfe_env *env, const uint64_t *tb, const uint64_t *serial) { return env->e.reset(tb, serial); }
+int sfe_step(sfe_env *env, const uint8_t *cmd) { return env->e.step_host(cmd); }
+int sfe_step_many(sfe_env *env, const uint8_t *cmds, int32_t k) { return env->e.step_device(cmds, k); }
+int sfe_observe(sfe_env *env, float *out) { return env->e.observe_host(out); }
+int sfe_results(sfe_env *env, int32_t *out) { return env->e.results_host(out); }
+int sfe_done(sfe_env *env, uint8_t *out) { return env->e.done_host(out); }
+int sfe_state_digest(sfe_env *env, uint64_t *out) { return env->e.state_digest(out); }
+int sfe_dump_arena(sfe_env *env, int32_t a, sf_arena_hdr *hdr, sf_human_rec *hs, sf_zombie_rec *zs, sf_bullet_rec *bs,
+                   sf_portal_rec *ps, uint8_t *cf, int32_t *cd, int32_t *cp) {
+  return env->e.dump_arena(a, hdr, hs, zs, bs, ps, cf, cd, cp);
+}
+const char *sfe_last_error(void) { return sf::last_error().c_str(); }
+}

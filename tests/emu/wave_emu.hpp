@@ -1,0 +1,157 @@
+// wave_emu.hpp — TEST INFRASTRUCTURE: a 64-lane wavefront emulated on the CPU.
+//
+// Implements the wave-backend interface that strikeforce_amd/csrc/sf_core.hpp is written against
+// (see wave_gfx950.hpp for the real one), so that the exact device source can be run, compared with the
+// oracle and put under AddressSanitizer on a machine without a GPU.  It is built only into
+// tests/emu/libsf_emu.so, which only tests/ loads; the product library never contains or calls it.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#define SF_DEV inline
+
+namespace sf {
+
+struct EmuP {
+  uint64_t m;
+};
+inline EmuP operator&(EmuP a, EmuP b) { return {a.m & b.m}; }
+inline EmuP operator|(EmuP a, EmuP b) { return {a.m | b.m}; }
+inline EmuP operator!(EmuP a) { return {~a.m}; }
+
+struct EmuV {
+  uint32_t v[64];
+  EmuV() {}
+  EmuV(uint32_t x) {
+    for (int i = 0; i < 64; ++i) v[i] = x;
+  }
+};
+#define EMU_BIN(op)                                              \
+  inline EmuV operator op(const EmuV &a, const EmuV &b) {        \
+    EmuV r;                                                      \
+    for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] op b.v[i];      \
+    return r;                                                    \
+  }                                                              \
+  inline EmuV operator op(const EmuV &a, uint32_t b) {           \
+    EmuV r;                                                      \
+    for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] op b;           \
+    return r;                                                    \
+  }
+EMU_BIN(+)
+EMU_BIN(-)
+EMU_BIN(*)
+EMU_BIN(&)
+EMU_BIN(|)
+EMU_BIN(^)
+#undef EMU_BIN
+inline EmuV operator<<(const EmuV &a, int s) {
+  EmuV r;
+  for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] << s;
+  return r;
+}
+inline EmuV operator>>(const EmuV &a, int s) {
+  EmuV r;
+  for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] >> s;
+  return r;
+}
+inline EmuV operator~(const EmuV &a) {
+  EmuV r;
+  for (int i = 0; i < 64; ++i) r.v[i] = ~a.v[i];
+  return r;
+}
+#define EMU_CMP(op)                                                                \
+  inline EmuP operator op(const EmuV &a, const EmuV &b) {                          \
+    EmuP r{0};                                                                     \
+    for (int i = 0; i < 64; ++i) r.m |= (uint64_t)(a.v[i] op b.v[i]) << i;         \
+    return r;                                                                      \
+  }                                                                                \
+  inline EmuP operator op(const EmuV &a, uint32_t b) {                             \
+    EmuP r{0};                                                                     \
+    for (int i = 0; i < 64; ++i) r.m |= (uint64_t)(a.v[i] op b) << i;              \
+    return r;                                                                      \
+  }
+EMU_CMP(==)
+EMU_CMP(!=)
+#undef EMU_CMP
+
+struct WaveEmu {
+  using V = EmuV;
+  using P = EmuP;
+
+  static V lane() {
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = (uint32_t)i;
+    return r;
+  }
+  static uint64_t ballot(P p) { return p.m; }
+  static int ctz64(uint64_t m) { return __builtin_ctzll(m); }
+  static int clz64(uint64_t m) { return __builtin_clzll(m); }
+  static uint32_t readlane(const V &v, uint32_t idx) { return v.v[idx & 63u]; }
+  static void setlane(V &v, uint32_t idx, uint32_t val) { v.v[idx & 63u] = val; }
+  static V select(P p, const V &a, const V &b) {
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = ((p.m >> i) & 1ull) ? a.v[i] : b.v[i];
+    return r;
+  }
+  static V sar31(const V &a) {
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = (uint32_t)((int32_t)a.v[i] >> 31);
+    return r;
+  }
+  static P le0(const V &a) {
+    P r{0};
+    for (int i = 0; i < 64; ++i) r.m |= (uint64_t)((int32_t)a.v[i] <= 0) << i;
+    return r;
+  }
+  static P ltu(const V &a, const V &b) {
+    P r{0};
+    for (int i = 0; i < 64; ++i) r.m |= (uint64_t)(a.v[i] < b.v[i]) << i;
+    return r;
+  }
+  static P ltu(const V &a, uint32_t b) {
+    P r{0};
+    for (int i = 0; i < 64; ++i) r.m |= (uint64_t)(a.v[i] < b) << i;
+    return r;
+  }
+  static P frombits(uint64_t m) { return P{m}; }
+  static uint32_t sum18(const V &a) {
+    uint32_t s = 0;
+    for (int i = 0; i < 32; ++i) s += a.v[i];  // rows 0 and 1, as the DPP reduction reads them
+    return s;
+  }
+  static V shl1(const V &a) {
+    V r;
+    for (int i = 0; i < 63; ++i) r.v[i] = a.v[i + 1];
+    r.v[63] = 0;
+    return r;
+  }
+  static V lds_u8(const uint8_t *lds, const V &idx, P pred) {
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
+    return r;
+  }
+  static uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return lds[idx]; }
+  static void ulds_store_u8(uint8_t *lds, uint32_t idx, uint32_t val) { lds[idx] = (uint8_t)val; }
+  static int32_t uload_i32(const int32_t *p) { return *p; }
+  static void ustore_i32(int32_t *p, int32_t v) { *p = v; }
+  static int32_t uload_i16(const int16_t *p) { return *p; }
+  static void ustore_i16(int16_t *p, int16_t v) { *p = v; }
+  static V gload(const uint32_t *base, const V &idx, P pred) {
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? base[idx.v[i]] : 0u;
+    return r;
+  }
+  static V gload_u8(const uint8_t *base, const V &idx, P pred) {
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? base[idx.v[i]] : 0u;
+    return r;
+  }
+  static void gstore(uint32_t *base, const V &idx, const V &val, P pred) {
+    for (int i = 0; i < 64; ++i)
+      if ((pred.m >> i) & 1ull) base[idx.v[i]] = val.v[i];
+  }
+  static void copy_g2l(uint8_t *lds, const uint8_t *g, uint32_t n) { memcpy(lds, g, n); }
+  static void copy_l2g(uint8_t *g, const uint8_t *lds, uint32_t n) { memcpy(g, lds, n); }
+};
+
+}  // namespace sf
