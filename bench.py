@@ -70,7 +70,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from strikeforce_amd import config, env
+    from strikeforce_amd import config, env, shard
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,13 +87,14 @@ def main():
 
     w = config.baseline_workload(args.workload, arenas=args.arenas, device=local)
     cfg = w.cfg
+    cfg.reseed_stride = world * args.arenas  # shards never reuse a seed
     g = env.ArenaBatch(w)
     g.set_stream(torch.cuda.current_stream().cuda_stream)
-    tb, sr = w.seeds(first_arena=rank * args.arenas)
+    tb, sr = shard.shard_seeds(w, rank)
     g.reset(tb, sr)
 
     total = args.warmup + args.steps
-    cmds, _ = config.bench_commands(args.arenas, cfg.n_agents, total, seed0=12345 + rank * args.arenas * cfg.n_agents)
+    cmds, _ = config.bench_commands(args.arenas, cfg.n_agents, total, seed0=shard.command_seed(w, rank))
     d_cmds = torch.from_numpy(cmds).cuda()  # resident in HBM before the timed region
     stride = args.arenas * cfg.n_agents
     res_local = torch.zeros(args.arenas * cfg.n_agents * 8, dtype=torch.int32, device="cuda")

@@ -97,7 +97,8 @@ typedef struct sf_config {
   int32_t level;            /* 1..10, gameplay.hpp:459 L */
   int32_t n_agents;         /* humans commanded through sf_step; agent 0 is the reference's `ind` */
   int32_t agent_team[SF_MAX_AGENTS]; /* BATTLE mode teams (server.cpp:239-246); ignored otherwise */
-  int32_t auto_reset;       /* re-seed (tb += arenas) and restart an arena when its episode ends */
+  int32_t auto_reset;       /* re-seed (tb += reseed_stride) and restart an arena when its episode ends */
+  int32_t reseed_stride;    /* 0 -> arenas; multi-GPU runs pass the global arena count so that shards never reuse a seed */
   int32_t timer_frames_per_level; /* frame clock replacing time(0) in Timer mode (gameplay.hpp:1145-1146); 0 -> 7500 */
   int32_t device;           /* HIP device ordinal */
   const char *map;          /* floors*rows*cols chars from {# . O ^ v}; map/floor*.txt, gameplay.hpp:1249-1274 */

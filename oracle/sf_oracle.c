@@ -941,7 +941,8 @@ static void o_step_arena(sfo_env *e, oarena *a, const uint8_t *ext) {
   if (a->done) {
     a->ended_last_step = 1;
     ++a->episodes;
-    if (e->cfg.auto_reset) o_reset_arena(e, a, a->tb + e->cfg.arenas, a->serial);
+    if (e->cfg.auto_reset)
+      o_reset_arena(e, a, a->tb + (e->cfg.reseed_stride > 0 ? e->cfg.reseed_stride : e->cfg.arenas), a->serial);
   }
 }
 

@@ -82,6 +82,7 @@ class Config(C.Structure):
         ("n_agents", C.c_int32),
         ("agent_team", C.c_int32 * MAX_AGENTS),
         ("auto_reset", C.c_int32),
+        ("reseed_stride", C.c_int32),
         ("timer_frames_per_level", C.c_int32),
         ("device", C.c_int32),
         ("map", C.c_char_p),

@@ -101,7 +101,7 @@ class Workload:
 
 def make_config(arenas, rows, cols, floors=1, H=1, Z=16, B=32, P=8, chests=9000, mode=abi.MODE_SOLO, level=1,
                 n_agents=1, teams=None, auto_reset=1, player_tokens=None, npc_tokens=None, device=0,
-                timer_frames=0):
+                timer_frames=0, reseed_stride=0):
     cfg = abi.Config()
     cfg.abi_version = abi.SF_ABI_VERSION
     cfg.arenas = arenas
@@ -111,6 +111,7 @@ def make_config(arenas, rows, cols, floors=1, H=1, Z=16, B=32, P=8, chests=9000,
     for i in range(abi.MAX_AGENTS):
         cfg.agent_team[i] = (teams[i] if teams and i < len(teams) else i + 1)
     cfg.auto_reset = auto_reset
+    cfg.reseed_stride = reseed_stride
     cfg.timer_frames_per_level = timer_frames
     cfg.device = device
     cfg.player = abi.Profile.from_tokens(player_tokens or HUMAN_ENEMY_TOKENS)

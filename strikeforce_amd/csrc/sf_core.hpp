@@ -896,7 +896,7 @@ struct Core {
       S.ended = 1;
       ++S.episodes;
       if (p.auto_reset) {
-        const uint64_t tb = (((uint64_t)S.tb_hi << 32) | S.tb_lo) + (uint64_t)p.A;
+        const uint64_t tb = (((uint64_t)S.tb_hi << 32) | S.tb_lo) + (uint64_t)(uint32_t)p.reseed;
         const uint64_t sr = ((uint64_t)S.sr_hi << 32) | S.sr_lo;
         const int32_t ep = S.episodes;
         reset(S, lds, p, a, tb, sr);

@@ -96,6 +96,7 @@ inline int validate(const sf_config *c) {
   if (c->cap_bullets < 1 || c->cap_bullets > SF_MAX_BULLETS) return fail(SF_ERR_ARG, "cap_bullets must be 1..256");
   if (c->cap_portals < 1 || c->cap_portals > SF_MAX_PORTALS) return fail(SF_ERR_ARG, "cap_portals must be 1..64");
   if (c->cap_chests < 0) return fail(SF_ERR_ARG, "cap_chests < 0");
+  if (c->reseed_stride < 0) return fail(SF_ERR_ARG, "reseed_stride < 0");
   if (c->n_agents < 1 || c->n_agents > SF_MAX_AGENTS || c->n_agents > c->cap_humans)
     return fail(SF_ERR_ARG, "n_agents must be 1..min(16, cap_humans)");
   if (c->level < 1 || c->level > 10) return fail(SF_ERR_ARG, "level must be 1..10");
@@ -183,6 +184,7 @@ struct Env {
     p.cells = cells, p.cells_pad = (cells + 15) & ~15;
     p.H = cfg.cap_humans, p.Z = cfg.cap_zombies, p.B = cfg.cap_bullets, p.P = cfg.cap_portals, p.C = cfg.cap_chests;
     p.mode = cfg.mode, p.level = cfg.level, p.n_agents = cfg.n_agents, p.auto_reset = cfg.auto_reset;
+    p.reseed = cfg.reseed_stride > 0 ? cfg.reseed_stride : cfg.arenas;
     p.timer_lim = cfg.level * (cfg.timer_frames_per_level > 0 ? cfg.timer_frames_per_level : 7500);
     p.squad_floor = cfg.floors > 2 ? 2 : cfg.floors - 1;
     NB = nb_for(p.B);
