@@ -155,9 +155,9 @@ struct HipRT {
 
   template <int NB>
   int do_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
-    int rc = lds_attr(k_reset<NB>, (size_t)p.cells_pad);
+    int rc = lds_attr(k_reset<NB>, lds_bytes_for(p.cells_pad));
     if (rc) return rc;
-    hipLaunchKernelGGL(k_reset<NB>, dim3((unsigned)p.A), dim3(64), (size_t)p.cells_pad, stream, p, tb, serial);
+    hipLaunchKernelGGL(k_reset<NB>, dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad), stream, p, tb, serial);
     SF_HIP(hipGetLastError());
     return SF_OK;
   }
@@ -173,7 +173,7 @@ struct HipRT {
 
   template <int NB>
   int do_step(const Params &p, const uint8_t *cmds, int k) {
-    int rc = lds_attr(k_step<NB>, (size_t)p.cells_pad);
+    int rc = lds_attr(k_step<NB>, lds_bytes_for(p.cells_pad));
     if (rc) return rc;
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (timing) {
@@ -186,7 +186,7 @@ struct HipRT {
       ev = &events[used_events++];
       SF_HIP(hipEventRecord(ev->first, stream));
     }
-    hipLaunchKernelGGL(k_step<NB>, dim3((unsigned)p.A), dim3(64), (size_t)p.cells_pad, stream, p, cmds, k);
+    hipLaunchKernelGGL(k_step<NB>, dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad), stream, p, cmds, k);
     SF_HIP(hipGetLastError());
     if (ev) SF_HIP(hipEventRecord(ev->second, stream));
     return SF_OK;

@@ -38,8 +38,8 @@ struct Core {
     V ba[NB], bd[NB], bb[NB], bc[NB];
     // portals (lane < P)
     V ppos;
-    // RNG (lane < 18): random[i], us[i], seed[i]  RN:31
-    V rv, rus, rseed;
+    // RNG (lane < 18): log_3(random[i]) (bit 16 set: random[i] == 0), us[i], seed[i]  RN:31
+    V rl, rus, rseed;
     // wave-uniform scalars  G:461
     int32_t frame, kills, tkills, loot, chests, steps, episodes, done, outcome, ended;
     uint32_t jomle, draws;
@@ -61,33 +61,40 @@ struct Core {
     return r + (W::sar31(r) & 65537u);
   }
 
-  static SF_DEV uint32_t draw(Arena &S) {  // RN:54-62
-    V x = S.rv;
-    V x2 = mulmod_v(x, x), x4 = mulmod_v(x2, x2), x8 = mulmod_v(x4, x4);
-    V s = S.rseed;  // 1..10: p[random[i]][seed[i]] = random[i]^seed[i]
-    V r = W::select((s & 1u) != 0u, x, V(1u));
-    r = W::select((s & 2u) != 0u, mulmod_v(r, x2), r);
-    r = W::select((s & 4u) != 0u, mulmod_v(r, x4), r);
-    r = W::select((s & 8u) != 0u, mulmod_v(r, x8), r);
-    uint32_t sum = W::sum18(S.rus * r) + 1u;  // rus is 0 on lanes >= 18; sum < 2^24
+  // Z/65537* is cyclic of order 65536 with generator 3, so x^e = 3^(log3(x) * e mod 65536).  The state keeps
+  // log3(random[i]); a power is then two 256-entry LDS lookups (3^lo, 3^(256 hi)) and one mulmod instead of a
+  // 16-step square-and-multiply chain, and the new value's log is one HBM/L2 lookup in the 64 Ki-entry log table.
+  // Bit-identical to RN:54-62 by construction (checked against the reference's known answers).
+  static constexpr uint32_t RL_ZERO = 0x10000u;  // random[i] == 0 (only until the first 18 draws after _srand)
+  static SF_DEV const uint32_t *exp_lo(const uint8_t *lds, const Params &p) {
+    return reinterpret_cast<const uint32_t *>(lds + p.cells_pad);
+  }
+  static SF_DEV V pow3_v(const uint8_t *lds, const Params &p, V m, P pred) {  // 3^m mod 65537, m < 65536
+    const uint32_t *t = exp_lo(lds, p);
+    return mulmod_v(W::lds_u32(t, m & 255u, pred), W::lds_u32(t + 256, m >> 8, pred));
+  }
+  static SF_DEV uint32_t pow3_u(const uint8_t *lds, const Params &p, uint32_t m) {
+    const uint32_t *t = exp_lo(lds, p);
+    return mulmod_u(W::ulds_u32(t, m & 255u), W::ulds_u32(t + 256, m >> 8));
+  }
+
+  static SF_DEV uint32_t draw(Arena &S, const uint8_t *lds, const Params &p) {  // RN:54-62
+    const P tap = W::ltu(W::lane(), 18u) & ((S.rl & RL_ZERO) == 0u);
+    const V pw = pow3_v(lds, p, (S.rl * S.rseed) & 0xffffu, tap);  // p[random[i]][seed[i]] = random[i]^seed[i]
+    uint32_t sum = W::sum18(W::select(tap, S.rus * pw, V(0u))) + 1u;  // < 2^24
     int32_t t = (int32_t)(sum & 0xffffu) - (int32_t)(sum >> 16);
     t += (t >> 31) & 65537;
     if (t == 0) t = 1;  // binpow(sum + (int)(sum == 0), ...)
     S.jomle += 1u;
-    uint32_t e = S.jomle & 0xffffu;  // b %= mod - 1
-    uint32_t res = 1u, a = (uint32_t)t;
-    while (e) {
-      if (e & 1u) res = mulmod_u(res, a);
-      a = mulmod_u(a, a);
-      e >>= 1;
-    }
-    S.rv = W::select(W::lane() == 17u, V(res), W::shl1(S.rv));  // the 17 swaps: rotate left, new value last
+    const uint32_t e = S.jomle & 0xffffu;  // b %= mod - 1
+    const uint32_t lnew = (W::uload_u16c(p.logt + (t - 1)) * e) & 0xffffu;
+    S.rl = W::select(W::lane() == 17u, V(lnew), W::shl1(S.rl));  // the 17 swaps: rotate left, new value last
     S.draws += 1u;
-    return res & 1023u;
+    return pow3_u(lds, p, lnew) & 1023u;
   }
 
-  static SF_DEV void srand_(Arena &S, uint64_t tb, uint64_t us) {  // RN:64-76
-    S.rv = V(0u), S.rus = V(0u), S.rseed = V(0u);
+  static SF_DEV void srand_(Arena &S, const uint8_t *lds, const Params &p, uint64_t tb, uint64_t us) {  // RN:64-76
+    S.rl = V(RL_ZERO), S.rus = V(0u), S.rseed = V(0u);
     for (int i = 0; i < 18; ++i) {
       W::setlane(S.rus, (uint32_t)i, (uint32_t)(us % 10u) + 1u);
       W::setlane(S.rseed, (uint32_t)i, (uint32_t)(tb % 10u) + 1u);
@@ -95,7 +102,7 @@ struct Core {
       tb /= 10u;
     }
     S.jomle = 18u;
-    for (int i = 0; i < 1024; ++i) draw(S);
+    for (int i = 0; i < 1024; ++i) draw(S, lds, p);
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -265,27 +272,27 @@ struct Core {
   // spawns G:532-572 (loop top G:1444-1449)
   static SF_DEV void spawn_chest(Arena &S, uint8_t *lds, const Params &p) {
     if (p.C <= S.chests) return;
-    int i = (int)(draw(S) % (uint32_t)p.F), j = (int)(draw(S) % (uint32_t)p.N), k = (int)(draw(S) % (uint32_t)p.M);
+    int i = (int)(draw(S, lds, p) % (uint32_t)p.F), j = (int)(draw(S, lds, p) % (uint32_t)p.N), k = (int)(draw(S, lds, p) % (uint32_t)p.M);
     uint32_t fl;
     if (showit(S, lds, p, i, j, k, fl) != SH_EMPTY) return;
-    uint32_t t = draw(S) % 4u;
+    uint32_t t = draw(S, lds, p) % 4u;
     W::ulds_store_u8(lds, cellidx(p, i, j, k), fl | SF_CELL_CHEST | (t << SF_CELL_CONS_SHIFT));
     S.dirty = 1u;
     ++S.chests;
   }
   static SF_DEV void spawn_zombie_npc(Arena &S, uint8_t *lds, const Params &p) {
-    int i = (int)(draw(S) % (uint32_t)p.F), j = (int)(draw(S) % (uint32_t)p.N), k = (int)(draw(S) % (uint32_t)p.M);
+    int i = (int)(draw(S, lds, p) % (uint32_t)p.F), j = (int)(draw(S, lds, p) % (uint32_t)p.N), k = (int)(draw(S, lds, p) % (uint32_t)p.M);
     uint32_t fl;
     if (showit(S, lds, p, i, j, k, fl) != SH_EMPTY) return;
     int index = z_ind(S, p);
     if (index == -1) return;
-    uint32_t super_ = (draw(S) % 4u == 0u) ? 1u : 0u;  // Zombie::gen_npc CH:850-857
+    uint32_t super_ = (draw(S, lds, p) % 4u == 0u) ? 1u : 0u;  // Zombie::gen_npc CH:850-857
     W::setlane(S.zpos, (uint32_t)index, pos_pack(i, j, k) | ZF_ALIVE | (super_ ? ZF_SUPER : 0u));
     W::setlane(S.zhp, (uint32_t)index, (super_ + 1u) * 400u);
     W::setlane(S.zmd, (uint32_t)index, (super_ + 1u) * 100u);
   }
   static SF_DEV void spawn_human_npc(Arena &S, uint8_t *lds, const Params &p) {
-    int i = (int)(draw(S) % (uint32_t)p.F), j = (int)(draw(S) % (uint32_t)p.N), k = (int)(draw(S) % (uint32_t)p.M);
+    int i = (int)(draw(S, lds, p) % (uint32_t)p.F), j = (int)(draw(S, lds, p) % (uint32_t)p.N), k = (int)(draw(S, lds, p) % (uint32_t)p.M);
     uint32_t fl;
     if (showit(S, lds, p, i, j, k, fl) != SH_EMPTY) return;
     int index = h_ind(S, p);
@@ -325,9 +332,9 @@ struct Core {
         }
       }
       if (!b) {
-        if (draw(S) % 5u < 2u) continue;
+        if (draw(S, lds, p) % 5u < 2u) continue;
         for (int i1 = 0; i1 < 2; ++i1) {
-          const int i2 = (int)(draw(S) % 4u);
+          const int i2 = (int)(draw(S, lds, p) % 4u);
           uint32_t fl;
           if (showit(S, lds, p, f, r + DX(i2), c + DY(i2), fl) == SH_EMPTY) {
             W::setlane(S.zpos, z, (zp & ~POS_MASK) | pos_pack(f, r + DX(i2), c + DY(i2)));
@@ -507,7 +514,7 @@ struct Core {
     bool any = false;
 #pragma unroll
     for (int j = 0; j < NB; ++j) any = any || W::ballot((S.ba[j] & BA_ALIVE) != 0u) != 0ull;
-    const uint32_t r = draw(S) & 1u;  // drawn even when no bullet is alive
+    const uint32_t r = draw(S, lds, p) & 1u;  // drawn even when no bullet is alive
     if (!any) return;
     uint64_t moved[NB];
 #pragma unroll
@@ -741,17 +748,17 @@ struct Core {
   }
 
   // human_rnpc_bot G:1927-1940
-  static SF_DEV uint32_t human_rnpc_bot(Arena &S) {
+  static SF_DEV uint32_t human_rnpc_bot(Arena &S, const uint8_t *lds, const Params &p) {
     if (S.frame % 50 <= 1) {
-      const uint32_t k = draw(S) % 8u;
+      const uint32_t k = draw(S, lds, p) % 8u;
       return (uint32_t)("cvbnm,./"[k]);
-    } else if (draw(S) % 5u < 3u)
+    } else if (draw(S, lds, p) % 5u < 3u)
       return 'x';
-    else if (draw(S) % 5u < 3u) {
-      const uint32_t k = draw(S) % 7u;
+    else if (draw(S, lds, p) % 5u < 3u) {
+      const uint32_t k = draw(S, lds, p) % 7u;
       return (uint32_t)("12awsdp"[k]);
     }
-    const uint32_t k = draw(S) % 8u;
+    const uint32_t k = draw(S, lds, p) % 8u;
     return (uint32_t)("+ufghj[]"[k]);
   }
 
@@ -766,10 +773,10 @@ struct Core {
       while (m) {
         const uint32_t i = (uint32_t)W::ctz64(m);
         m &= m - 1ull;
-        W::setlane(S.hcmd, i, human_rnpc_bot(S));
+        W::setlane(S.hcmd, i, human_rnpc_bot(S, lds, p));
       }
     }
-    const uint32_t r = draw(S) & 1u;
+    const uint32_t r = draw(S, lds, p) & 1u;
     uint64_t m = alive;
     while (m) {
       const uint32_t i = r ? (uint32_t)W::ctz64(m) : (uint32_t)(63 - W::clz64(m));
@@ -844,16 +851,16 @@ struct Core {
     S.ppos = W::gload(p.map_exits, W::lane(), W::ltu(W::lane(), (uint32_t)p.P));
     W::copy_g2l(lds, p.map_flags, (uint32_t)p.cells_pad);
     S.dirty = 1u;
-    srand_(S, tb, serial);
+    srand_(S, lds, p, tb, serial);
     if (p.mode == SF_MODE_BATTLE) {  // G:1846-1859
       for (int i = 0; i < p.n_agents; ++i)
         human_make(S, p, (uint32_t)i, 0, POS_NONE, 1, p.tab->teams[i], HF_CTRL | (i ? HF_REMOTE : 0u));
       // not yet on the map: clear the designation until placed
       S.hfl = S.hfl & ~HF_OCC;
       for (int i = 0; i < p.n_agents; ++i) {
-        const uint32_t way = draw(S) % 4u + 1u;
+        const uint32_t way = draw(S, lds, p) % 4u + 1u;
         for (int guard = 0; guard < (1 << 20); ++guard) {  // `while(true)` with an exit every wave reaches
-          int f = (int)(draw(S) % (uint32_t)p.F), r = (int)(draw(S) % (uint32_t)p.N), c = (int)(draw(S) % (uint32_t)p.M);
+          int f = (int)(draw(S, lds, p) % (uint32_t)p.F), r = (int)(draw(S, lds, p) % (uint32_t)p.N), c = (int)(draw(S, lds, p) % (uint32_t)p.M);
           uint32_t fl;
           if (showit(S, lds, p, f, r, c, fl) == SH_EMPTY) {
             W::setlane(S.hpos, (uint32_t)i, pos_pack(f, r, c));
@@ -940,8 +947,12 @@ struct Core {
     S.ppos = W::gload(p.por + (size_t)a * (size_t)p.P, ln, W::ltu(ln, (uint32_t)p.P));
     {
       // one dword per tap: random[i] | us[i] << 20 | seed[i] << 24  (RN:31; us/seed are decimal digits + 1)
-      const V rw = W::gload(p.rng + (size_t)a * RNG_WORDS, ln, W::ltu(ln, 18u));
-      S.rv = rw & 0xfffffu, S.rus = (rw >> 20) & 15u, S.rseed = (rw >> 24) & 15u;
+      const P in = W::ltu(ln, 18u);
+      const V rw = W::gload(p.rng + (size_t)a * RNG_WORDS, ln, in);
+      const V val = rw & 0xfffffu;
+      S.rus = (rw >> 20) & 15u, S.rseed = (rw >> 24) & 15u;
+      const P nz = in & (val != 0u);
+      S.rl = W::select(nz, W::gload_u16(p.logt, val - 1u, nz), V(RL_ZERO));
     }
     const V sc = W::gload((const uint32_t *)p.scal + (size_t)a * SC_WORDS, ln, W::ltu(ln, (uint32_t)SC_WORDS));
     S.frame = (int32_t)W::readlane(sc, SC_FRAME), S.kills = (int32_t)W::readlane(sc, SC_KILLS);
@@ -986,7 +997,11 @@ struct Core {
       W::gstore(b + BW_B * AB, sl, S.bb[j], in), W::gstore(b + BW_C * AB, sl, S.bc[j], in);
     }
     W::gstore(p.por + (size_t)a * (size_t)p.P, ln, S.ppos, W::ltu(ln, (uint32_t)p.P));
-    W::gstore(p.rng + (size_t)a * RNG_WORDS, ln, S.rv | (S.rus << 20) | (S.rseed << 24), W::ltu(ln, 18u));
+    {
+      const P in = W::ltu(ln, 18u), nz = in & ((S.rl & RL_ZERO) == 0u);
+      const V val = W::select(nz, pow3_v(lds, p, S.rl & 0xffffu, nz), V(0u));
+      W::gstore(p.rng + (size_t)a * RNG_WORDS, ln, val | (S.rus << 20) | (S.rseed << 24), in);
+    }
     V sc = V(0u);
     W::setlane(sc, SC_FRAME, (uint32_t)S.frame), W::setlane(sc, SC_KILLS, (uint32_t)S.kills);
     W::setlane(sc, SC_TKILLS, (uint32_t)S.tkills), W::setlane(sc, SC_LOOT, (uint32_t)S.loot);
@@ -1006,6 +1021,7 @@ struct Core {
   static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial) {
     Arena S;
     S.episodes = 0, S.ended = 0;
+    W::copy_g2l(lds + p.cells_pad, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
     reset(S, lds, p, a, tb[a], serial[a]);
     store(S, lds, p, a);
   }
@@ -1013,6 +1029,7 @@ struct Core {
   // cmds: [k][A][n_agents]
   static SF_DEV void step_body(uint8_t *lds, const Params &p, int a, const uint8_t *cmds, int k) {
     Arena S;
+    W::copy_g2l(lds + p.cells_pad, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
     load(S, lds, p, a);
     const P ag = W::ltu(W::lane(), (uint32_t)p.n_agents);
     for (int s = 0; s < k; ++s) {

@@ -152,6 +152,8 @@ struct Env {
   uint8_t *d_map_flags = nullptr;
   int16_t *d_map_pidx = nullptr;
   uint32_t *d_map_exits = nullptr;
+  uint16_t *d_logt = nullptr;
+  uint32_t *d_exptab = nullptr;
   uint64_t *d_tb = nullptr, *d_serial = nullptr;
   uint8_t *d_cmd = nullptr;
   float *d_obs = nullptr;
@@ -188,7 +190,7 @@ struct Env {
     p.timer_lim = cfg.level * (cfg.timer_frames_per_level > 0 ? cfg.timer_frames_per_level : 7500);
     p.squad_floor = cfg.floors > 2 ? 2 : cfg.floors - 1;
     NB = nb_for(p.B);
-    if ((size_t)p.cells_pad > rt.max_lds()) return fail(SF_ERR_ARG, "map does not fit the 160 KiB LDS flag plane");
+    if (lds_bytes_for(p.cells_pad) > rt.max_lds()) return fail(SF_ERR_ARG, "map does not fit the 160 KiB LDS flag plane");
     // tables
     derive_profile(cfg, cfg.player, tab.der[0]);
     derive_profile(cfg, cfg.npc, tab.der[1]);
@@ -222,9 +224,21 @@ struct Env {
       }
     }
     cfg.map = nullptr, cfg.map_portal = nullptr;  // the caller's buffers are not kept
+    // RNG tables: discrete logs / powers of the generator 3 of Z/65537*
+    std::vector<uint16_t> logt(65536);
+    std::vector<uint32_t> exptab(512);
+    {
+      uint32_t v = 1;
+      for (uint32_t m = 0; m < 65536; ++m) {
+        logt[v - 1] = (uint16_t)m;
+        if (m < 256) exptab[m] = v;
+        if ((m & 255u) == 0) exptab[256 + (m >> 8)] = v;
+        v = (uint32_t)(((uint64_t)v * 3u) % 65537u);
+      }
+    }
     // device state
     const size_t A = (size_t)p.A;
-    if ((rc = alloc(d_tab, 1)) || (rc = alloc(d_map_flags, (size_t)p.cells_pad)) || (rc = alloc(d_map_pidx, (size_t)cells)) ||
+    if ((rc = alloc(d_logt, 65536)) || (rc = alloc(d_exptab, 512)) || (rc = alloc(d_tab, 1)) || (rc = alloc(d_map_flags, (size_t)p.cells_pad)) || (rc = alloc(d_map_pidx, (size_t)cells)) ||
         (rc = alloc(d_map_exits, (size_t)p.P)) || (rc = alloc(p.hum, HW_WORDS * A * p.H)) ||
         (rc = alloc(p.zom, ZW_WORDS * A * p.Z)) || (rc = alloc(p.bul, BW_WORDS * A * p.B)) ||
         (rc = alloc(p.por, A * p.P)) || (rc = alloc(p.rng, A * RNG_WORDS)) || (rc = alloc(p.scal, A * SC_WORDS)) ||
@@ -233,17 +247,21 @@ struct Env {
         (rc = alloc(d_tb, A)) || (rc = alloc(d_serial, A)) || (rc = alloc(d_cmd, A * p.n_agents)))
       return rc;
     rt.h2d(d_tab, &tab, sizeof tab);
+    rt.h2d(d_logt, logt.data(), logt.size() * sizeof(uint16_t));
+    rt.h2d(d_exptab, exptab.data(), exptab.size() * sizeof(uint32_t));
+    if ((rc = rt.sync())) return rc;  // the staging vectors above die with this scope
     rt.h2d(d_map_flags, map_flags.data(), map_flags.size());
     rt.h2d(d_map_pidx, map_pidx.data(), map_pidx.size() * sizeof(int16_t));
     rt.h2d(d_map_exits, map_exits.data(), map_exits.size() * sizeof(uint32_t));
     rt.zero(p.results, A * p.n_agents * 8 * sizeof(int32_t));
     rt.zero(p.scal, A * SC_WORDS * sizeof(int32_t));
+    p.logt = d_logt, p.exptab = d_exptab;
     p.tab = d_tab, p.map_flags = d_map_flags, p.map_pidx = d_map_pidx, p.map_exits = d_map_exits;
     return rt.sync();
   }
 
   void destroy() {
-    void *ptrs[] = {d_tab, d_map_flags, d_map_pidx, d_map_exits, p.hum, p.zom, p.bul, p.por, p.rng, p.scal, p.results,
+    void *ptrs[] = {d_logt, d_exptab, d_tab, d_map_flags, d_map_pidx, d_map_exits, p.hum, p.zom, p.bul, p.por, p.rng, p.scal, p.results,
                     p.flags, p.aux_dmg, p.aux_pidx, d_tb, d_serial, d_cmd, d_obs};
     for (void *q : ptrs)
       if (q) rt.free(q);

@@ -97,8 +97,12 @@ struct Params {
   const uint8_t *map_flags;  // [cells_pad]
   const int16_t *map_pidx;   // [cells]
   const uint32_t *map_exits; // [P]
+  const uint16_t *logt;      // [65536] log_3(v) for v = 1..65536 at index v-1 (RNG, sf_core.hpp draw())
+  const uint32_t *exptab;    // [512] 3^i (i < 256) then 3^(256 i): staged in LDS behind the flag plane
 };
 
 inline int nb_for(int B) { return (B + 63) / 64; }
+constexpr int LDS_TABLE_BYTES = 2048;  // exptab
+inline size_t lds_bytes_for(int cells_pad) { return (size_t)cells_pad + LDS_TABLE_BYTES; }
 
 }  // namespace sf

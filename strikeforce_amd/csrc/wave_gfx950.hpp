@@ -48,6 +48,8 @@ struct WaveGfx950 {
   // LDS flag plane
   static SF_DEV V lds_u8(const uint8_t *lds, V idx, P pred) { return pred ? (uint32_t)lds[idx] : 0u; }
   static SF_DEV uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return uni((uint32_t)lds[idx]); }
+  static SF_DEV V lds_u32(const uint32_t *lds, V idx, P pred) { return pred ? lds[idx] : 0u; }
+  static SF_DEV uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return uni(lds[idx]); }
   static SF_DEV void ulds_store_u8(uint8_t *lds, uint32_t idx, uint32_t val) {
     lds[idx] = (uint8_t)val;  // every lane writes the same byte: no divergence, one LDS pass
     __builtin_amdgcn_wave_barrier();
@@ -61,6 +63,9 @@ struct WaveGfx950 {
   static SF_DEV void ustore_i32(int32_t *p, int32_t v) {
     if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
+  // read-only table (never written by a kernel): plain load, the compiler may use the scalar cache
+  static SF_DEV uint32_t uload_u16c(const uint16_t *p) { return uni((uint32_t)*p); }
+  static SF_DEV V gload_u16(const uint16_t *base, V idx, P pred) { return pred ? (uint32_t)base[idx] : 0u; }
   static SF_DEV int32_t uload_i16(const int16_t *p) {
     return (int32_t)(int16_t)uni((uint32_t)(uint16_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
   }

@@ -17,12 +17,12 @@ namespace sf {
 
 template <int NB>
 static void run_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
-  std::vector<uint8_t> lds((size_t)p.cells_pad);
+  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad));
   for (int a = 0; a < p.A; ++a) Core<WaveEmu, NB>::reset_body(lds.data(), p, a, tb, serial);
 }
 template <int NB>
 static void run_step(const Params &p, const uint8_t *cmds, int k) {
-  std::vector<uint8_t> lds((size_t)p.cells_pad);
+  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad));
   for (int a = 0; a < p.A; ++a) Core<WaveEmu, NB>::step_body(lds.data(), p, a, cmds, k);
 }
 

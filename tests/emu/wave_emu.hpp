@@ -131,6 +131,18 @@ struct WaveEmu {
     return r;
   }
   static uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return lds[idx]; }
+  static V lds_u32(const uint32_t *lds, const V &idx, P pred) {
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
+    return r;
+  }
+  static uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return lds[idx]; }
+  static uint32_t uload_u16c(const uint16_t *p) { return *p; }
+  static V gload_u16(const uint16_t *base, const V &idx, P pred) {
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? base[idx.v[i]] : 0u;
+    return r;
+  }
   static void ulds_store_u8(uint8_t *lds, uint32_t idx, uint32_t val) { lds[idx] = (uint8_t)val; }
   static int32_t uload_i32(const int32_t *p) { return *p; }
   static void ustore_i32(int32_t *p, int32_t v) { *p = v; }
