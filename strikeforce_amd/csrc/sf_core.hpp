@@ -78,19 +78,23 @@ struct Core {
     return mulmod_u(W::ulds_u32(t, m & 255u), W::ulds_u32(t + 256, m >> 8));
   }
 
+  // The scalar unit is shared by the four SIMDs of a CU and is this kernel's scarcest resource (measured:
+  // SQ_INSTS_SALU ~ SQ_INSTS_VALU, one scalar issue per cycle per CU), so the wave-uniform tail of a draw
+  // (mod, log lookup, power) is deliberately computed on the vector unit, redundantly in every lane, and only the
+  // 10-bit result goes back to an SGPR.
   static SF_DEV uint32_t draw(Arena &S, const uint8_t *lds, const Params &p) {  // RN:54-62
     const P tap = W::ltu(W::lane(), 18u) & ((S.rl & RL_ZERO) == 0u);
     const V pw = pow3_v(lds, p, (S.rl * S.rseed) & 0xffffu, tap);  // p[random[i]][seed[i]] = random[i]^seed[i]
-    uint32_t sum = W::sum18(W::select(tap, S.rus * pw, V(0u))) + 1u;  // < 2^24
-    int32_t t = (int32_t)(sum & 0xffffu) - (int32_t)(sum >> 16);
-    t += (t >> 31) & 65537;
-    if (t == 0) t = 1;  // binpow(sum + (int)(sum == 0), ...)
+    const V sum = W::vec(W::sum18(W::select(tap, S.rus * pw, V(0u))) + 1u);  // < 2^24, same in every lane
+    V t = (sum & 0xffffu) - (sum >> 16);
+    t = t + (W::sar31(t) & 65537u);
+    t = W::select(t == 0u, V(1u), t);  // binpow(sum + (int)(sum == 0), ...)
     S.jomle += 1u;
     const uint32_t e = S.jomle & 0xffffu;  // b %= mod - 1
-    const uint32_t lnew = (W::uload_u16c(p.logt + (t - 1)) * e) & 0xffffu;
-    S.rl = W::select(W::lane() == 17u, V(lnew), W::shl1(S.rl));  // the 17 swaps: rotate left, new value last
+    const V lnew = (W::gload_u16(p.logt, t - 1u, W::all()) * e) & 0xffffu;
+    S.rl = W::select(W::lane() == 17u, lnew, W::shl1(S.rl));  // the 17 swaps: rotate left, new value last
     S.draws += 1u;
-    return pow3_u(lds, p, lnew) & 1023u;
+    return W::first(pow3_v(lds, p, lnew, W::all()) & 1023u);
   }
 
   static SF_DEV void srand_(Arena &S, const uint8_t *lds, const Params &p, uint64_t tb, uint64_t us) {  // RN:64-76
@@ -301,24 +305,65 @@ struct Core {
   }
 
   // ------------------------------------------------------------------------------------------------
-  // zombie_action G:654-693: slot-ordered, wave-uniform loop over live zombies
+  // zombie_action G:654-693.  What a zombie may do depends on: a designated bullet on its own cell (skip), a
+  // human on a neighbour cell (punch instead of moving), and for a move the target being '.', i.e. a clear flag
+  // byte with no human, zombie or designated bullet on it.  Humans, flags and pre-existing bullets do not change
+  // during the phase and the punches it creates land on human cells, which border only zombies that do not move;
+  // so everything except "is another zombie there now" is computed once, lane-parallel, one lane per zombie, and
+  // the slot-ordered loop that fixes the RNG draw order only tests bits, draws, and asks one ballot per move.
   static SF_DEV void zombie_action(Arena &S, uint8_t *lds, const Params &p) {
-    uint64_t zm = W::ballot((S.zpos & ZF_ALIVE) != 0u) & capmask(p.Z);
+    const P zalive = ((S.zpos & ZF_ALIVE) != 0u) & W::ltu(W::lane(), (uint32_t)p.Z);
+    uint64_t zm = W::ballot(zalive);
+    if (!zm) return;
+    const V zq = S.zpos & POS_MASK;
+    const V zr = (zq >> 10) & 1023u, zc = zq & 1023u;
+    // neighbour d of each zombie: packed position and "clear flag byte" bit
+    V freebits = V(0u);
+    for (int d = 0; d < 4; ++d) {
+      const V rr = zr + (uint32_t)DX(d), cc = zc + (uint32_t)DY(d);
+      const P inb = zalive & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
+      const V ci = ((zq >> 20) * (uint32_t)p.N + rr) * (uint32_t)p.M + cc;
+      const V fl = W::lds_u8(lds, ci, inb);
+      freebits = freebits | W::select(inb & (fl == 0u), V(1u << d), V(0u));
+    }
+    const V qn0 = zq + 1024u, qn1 = zq + 1u, qn2 = zq - 1024u, qn3 = zq - 1u;  // DX/DY order: down, right, up, left
+    // designated bullets present at phase start: own cell -> skip; neighbour cell -> not '.'
+    uint64_t skip = 0ull;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      uint64_t bm = W::ballot((S.ba[j] & BA_REF) != 0u);
+      while (bm) {
+        const uint32_t l = (uint32_t)W::ctz64(bm);
+        bm &= bm - 1ull;
+        const uint32_t q = W::readlane(S.ba[j], l) & POS_MASK;
+        skip |= W::ballot(zalive & (zq == q));
+        const V hit = W::select(qn0 == q, V(1u), V(0u)) | W::select(qn1 == q, V(2u), V(0u)) |
+                      W::select(qn2 == q, V(4u), V(0u)) | W::select(qn3 == q, V(8u), V(0u));
+        freebits = freebits & ~hit;
+      }
+    }
+    // humans (cell designation s[0]) next to a zombie
+    uint64_t near = 0ull;
+    {
+      uint64_t hm = W::ballot((S.hfl & HF_OCC) != 0u);
+      while (hm) {
+        const uint32_t h = (uint32_t)W::ctz64(hm);
+        hm &= hm - 1ull;
+        const uint32_t q = W::readlane(S.hpos, h);
+        near |= W::ballot(zalive & ((qn0 == q) | (qn1 == q) | (qn2 == q) | (qn3 == q)));
+      }
+    }
     while (zm) {
       const uint32_t z = (uint32_t)W::ctz64(zm);
-      zm &= zm - 1ull;
-      const uint32_t zp = W::readlane(S.zpos, z);
-      const uint32_t q0 = zp & POS_MASK;
-      const int f = pos_f(q0), r = pos_r(q0), c = pos_c(q0);
-      if (refbullet_at(S, q0) >= 0) continue;
-      bool b = false;
-      // one ballot decides the common "no human next to me" case; the packed compare of an
-      // out-of-range neighbour (row/col -1) matches nobody
-      const P occ = (S.hfl & HF_OCC) != 0u;
-      const uint64_t near = W::ballot(occ & ((S.hpos == q0 + 1024u) | (S.hpos == q0 + 1u) | (S.hpos == q0 - 1024u) |
-                                             (S.hpos == q0 - 1u)));
-      if (near) {
+      const uint64_t bit = zm & (0ull - zm);
+      zm ^= bit;
+      if (skip & bit) continue;  // `if(themap[i][j][k].s[2]) continue;`
+      if (near & bit) {
+        // exact neighbour scan (the packed compare above can alias across a row end; this cannot)
+        const uint32_t q0 = W::readlane(zq, z);
+        const int f = pos_f(q0), r = pos_r(q0), c = pos_c(q0);
         const int zmd = (int)W::readlane(S.zmd, z);
+        bool b = false;
         for (int i1 = 0; i1 < 4; ++i1) {
           const int rr = r + DX(i1), cc = c + DY(i1);
           if (!inmap(p, rr, cc)) continue;
@@ -330,17 +375,19 @@ struct Core {
             b = true;
           }
         }
+        if (b) continue;
       }
-      if (!b) {
-        if (draw(S, lds, p) % 5u < 2u) continue;
-        for (int i1 = 0; i1 < 2; ++i1) {
-          const int i2 = (int)(draw(S, lds, p) % 4u);
-          uint32_t fl;
-          if (showit(S, lds, p, f, r + DX(i2), c + DY(i2), fl) == SH_EMPTY) {
-            W::setlane(S.zpos, z, (zp & ~POS_MASK) | pos_pack(f, r + DX(i2), c + DY(i2)));
-            break;
-          }
-        }
+      if (draw(S, lds, p) % 5u < 2u) continue;
+      const uint32_t fb = W::readlane(freebits, z);
+      const uint32_t zp = W::readlane(S.zpos, z);
+      for (int i1 = 0; i1 < 2; ++i1) {
+        const uint32_t i2 = draw(S, lds, p) % 4u;
+        if (!((fb >> i2) & 1u)) continue;
+        const uint32_t q = (zp & POS_MASK) + (i2 == 0u ? 1024u : i2 == 1u ? 1u : i2 == 2u ? 0u - 1024u : 0u - 1u);
+        // a human cannot be there: a zombie with a human neighbour never reaches this point
+        if (zombie_at(S, q) >= 0) continue;
+        W::setlane(S.zpos, z, (zp & ~POS_MASK) | q);
+        break;
       }
     }
   }

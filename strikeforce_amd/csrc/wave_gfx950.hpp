@@ -32,6 +32,15 @@ struct WaveGfx950 {
   static SF_DEV P le0(V v) { return (int32_t)v <= 0; }
   static SF_DEV P ltu(V a, V b) { return a < b; }
   static SF_DEV P frombits(uint64_t m) { return (m >> threadIdx.x) & 1ull; }
+  static SF_DEV P all() { return true; }
+  // a wave-uniform value moved to a VGPR behind the optimiser's back, so that what is computed from it stays on
+  // the vector unit (the scalar unit is shared by the CU's four SIMDs and is this kernel's bottleneck)
+  static SF_DEV V vec(uint32_t x) {
+    uint32_t r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+  }
+  static SF_DEV uint32_t first(V v) { return uni(v); }
 
   // sum over lanes 0..17 of a value that is zero on lanes >= 18: two DPP row reductions + two readlanes
   static SF_DEV uint32_t sum18(V v) {

@@ -114,6 +114,9 @@ struct WaveEmu {
     return r;
   }
   static P frombits(uint64_t m) { return P{m}; }
+  static P all() { return P{~0ull}; }
+  static V vec(uint32_t x) { return V(x); }
+  static uint32_t first(const V &v) { return v.v[0]; }
   static uint32_t sum18(const V &a) {
     uint32_t s = 0;
     for (int i = 0; i < 32; ++i) s += a.v[i];  // rows 0 and 1, as the DPP reduction reads them
