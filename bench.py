@@ -34,6 +34,17 @@ def algorithmic_bytes_per_step(cfg, observe=False):
     return b
 
 
+def pmc_traffic(workload, arenas, kpl):
+    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected in
+    their own runs and corrected as MI355X_MICROARCH.md prescribes; tools/summarize_prof.py), or None if this
+    launch shape was not profiled."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        return d["%s/%d/%d" % (workload, arenas, kpl)]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(workload_name, seconds=12.0):
     """The oracle (a single-threaded CPU port of the reference loop) timed on this host, on a bounded sample:
     64 arenas of the same workload, as many 250-step rounds as fit in ~`seconds`."""
@@ -125,6 +136,29 @@ def main():
     dt = time.perf_counter() - t0
     k_ms, k_launches = g.kernel_time(False)
 
+    # the interactive loop an RL learner runs: one launch per step (K = 1) + the observation of every agent
+    obs_n = 40
+    d_obs = torch.empty(args.arenas * cfg.n_agents * 30752, dtype=torch.float32, device="cuda")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    g.observe_device(d_obs.data_ptr())
+    torch.cuda.synchronize()
+    ev[0].record()
+    for s in range(obs_n):
+        g.step_device(d_cmds.data_ptr() + (s % total) * stride, 1)
+        g.observe_device(d_obs.data_ptr())
+    ev[1].record()
+    for s in range(obs_n):
+        g.observe_device(d_obs.data_ptr())
+    ev[2].record()
+    for s in range(obs_n):
+        g.step_device(d_cmds.data_ptr() + (s % total) * stride, 1)
+    ev[3].record()
+    torch.cuda.synchronize()
+    loop_ms = ev[0].elapsed_time(ev[1]) / obs_n
+    obs_ms = ev[1].elapsed_time(ev[2]) / obs_n
+    k1_ms = ev[2].elapsed_time(ev[3]) / obs_n
+    g.kernel_time(False)
+
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -156,9 +190,18 @@ def main():
                        "arenas_per_gpu": args.arenas, "steps_per_launch": args.k_per_launch,
                        "parallelism": "arena-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, args.arenas, args.k_per_launch),
                          "kernel": "k_step", "launches": k_launches, "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_arena_step": bytes_step},
+        }
+        obs_bytes = args.arenas * cfg.n_agents * (30752 * 4 + 961 * 8)
+        out["interactive"] = {
+            "what": "per rank: K=1 launch per step + sf_observe_device for every agent, %d steps" % obs_n,
+            "env_steps_per_s": world * args.arenas / (loop_ms / 1e3),
+            "ms_per_step": loop_ms, "k_step_K1_ms": k1_ms, "k_observe_ms": obs_ms,
+            "k_observe_roofline": {"bound": "hbm", "achieved": obs_bytes / (obs_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": obs_bytes / (obs_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_agent_step": 30752 * 4 + 961 * 8},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)

@@ -9,8 +9,24 @@
 #include <stdint.h>
 
 #define SF_DEV __device__ __forceinline__
+#define SF_NOINLINE __device__ __attribute__((noinline))
 
 namespace sf {
+
+// HBM pointers reach the kernels inside a by-value struct, where clang leaves them in the generic address
+// space (flat_load/flat_store, which also tie up the LDS counter).  Every HBM access below goes through these
+// casts so that it is a global_load/global_store.
+#define SF_GLOBAL __attribute__((address_space(1)))
+template <class T>
+static __device__ __forceinline__ const SF_GLOBAL T *gptr(const T *p) {
+  return (const SF_GLOBAL T *)p;
+}
+template <class T>
+static __device__ __forceinline__ SF_GLOBAL T *gptr(T *p) {
+  return (SF_GLOBAL T *)p;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // 16 B per lane; a builtin vector, usable in any address space
 
 struct WaveGfx950 {
   using V = uint32_t;
@@ -67,38 +83,38 @@ struct WaveGfx950 {
   // wave-uniform access to the sparse per-cell side tables in HBM (rare path).  Relaxed atomics keep
   // these on the vector memory path, which is coherent with this wave's own earlier stores.
   static SF_DEV int32_t uload_i32(const int32_t *p) {
-    return (int32_t)uni((uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+    return (int32_t)uni((uint32_t)__hip_atomic_load(gptr(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
   }
   static SF_DEV void ustore_i32(int32_t *p, int32_t v) {
-    if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (threadIdx.x == 0) __hip_atomic_store(gptr(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
   // read-only table (never written by a kernel): plain load, the compiler may use the scalar cache
-  static SF_DEV uint32_t uload_u16c(const uint16_t *p) { return uni((uint32_t)*p); }
-  static SF_DEV V gload_u16(const uint16_t *base, V idx, P pred) { return pred ? (uint32_t)base[idx] : 0u; }
+  static SF_DEV uint32_t uload_u16c(const uint16_t *p) { return uni((uint32_t)*gptr(p)); }
+  static SF_DEV V gload_u16(const uint16_t *base, V idx, P pred) { return pred ? (uint32_t)gptr(base)[idx] : 0u; }
   static SF_DEV int32_t uload_i16(const int16_t *p) {
-    return (int32_t)(int16_t)uni((uint32_t)(uint16_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+    return (int32_t)(int16_t)uni((uint32_t)(uint16_t)__hip_atomic_load(gptr(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
   }
   static SF_DEV void ustore_i16(int16_t *p, int16_t v) {
-    if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (threadIdx.x == 0) __hip_atomic_store(gptr(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
 
   // per-lane HBM access (struct-of-arrays: consecutive lanes hit consecutive dwords)
-  static SF_DEV V gload(const uint32_t *base, V idx, P pred) { return pred ? base[idx] : 0u; }
-  static SF_DEV V gload_u8(const uint8_t *base, V idx, P pred) { return pred ? (uint32_t)base[idx] : 0u; }
+  static SF_DEV V gload(const uint32_t *base, V idx, P pred) { return pred ? gptr(base)[idx] : 0u; }
+  static SF_DEV V gload_u8(const uint8_t *base, V idx, P pred) { return pred ? (uint32_t)gptr(base)[idx] : 0u; }
   static SF_DEV void gstore(uint32_t *base, V idx, V val, P pred) {
-    if (pred) base[idx] = val;
+    if (pred) gptr(base)[idx] = val;
   }
 
   // flag plane <-> LDS, 16 B per lane per pass (nbytes is a multiple of 16)
   static SF_DEV void copy_g2l(uint8_t *lds, const uint8_t *g, uint32_t nbytes) {
     for (uint32_t off = threadIdx.x * 16u; off < nbytes; off += 64u * 16u)
-      *reinterpret_cast<uint4 *>(lds + off) = *reinterpret_cast<const uint4 *>(g + off);
+      *reinterpret_cast<u32x4 *>(lds + off) = *reinterpret_cast<const SF_GLOBAL u32x4 *>(gptr(g) + off);
     __builtin_amdgcn_wave_barrier();
   }
   static SF_DEV void copy_l2g(uint8_t *g, const uint8_t *lds, uint32_t nbytes) {
     __builtin_amdgcn_wave_barrier();
     for (uint32_t off = threadIdx.x * 16u; off < nbytes; off += 64u * 16u)
-      *reinterpret_cast<uint4 *>(g + off) = *reinterpret_cast<const uint4 *>(lds + off);
+      *reinterpret_cast<SF_GLOBAL u32x4 *>(gptr(g) + off) = *reinterpret_cast<const u32x4 *>(lds + off);
   }
 };
 

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #define SF_DEV inline
+#define SF_NOINLINE inline
 
 namespace sf {
 
