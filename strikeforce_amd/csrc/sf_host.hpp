@@ -203,6 +203,24 @@ struct Env {
       if (cfg.agent_team[i] < 0 || cfg.agent_team[i] > 255) return fail(SF_ERR_ARG, "agent_team must be 0..255");
       tab.teams[i] = cfg.agent_team[i];
     }
+    {  // observation fast map (sf_obs.hpp obs_map_fast): constants of describe(), Custom.hpp:98,110-111,117-121
+      float in[16];
+      int n = 0;
+      auto add = [&](float x) {
+        if (x == 0.f) return;
+        for (int i = 0; i < n; ++i)
+          if (in[i] == x) return;
+        if (n < 16) in[n++] = x;
+      };
+      add(1.0f), add((float)0.01), add((float)(20 / 1000.0)), add((float)(10 / 1000.0));
+      for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 3; ++k) add((float)(cfg.items.cons[i][k] / 1000.0));
+      tab.obs_n = n;
+      for (int i = 0; i < n; ++i) {
+        tab.obs_in[i] = in[i];
+        tab.obs_out[i] = (float)pow((double)(fabsf(in[i]) / 10), 0.2);  // Custom.hpp:157, host libm
+      }
+    }
     // static map: gameplay.hpp:1249-1274
     map_flags.assign((size_t)p.cells_pad, 0);
     map_pidx.assign((size_t)cells, -1);

@@ -58,80 +58,67 @@ SF_HD inline void obs_damage_effect(const Derived &d, uint32_t fl, int32_t stami
   }
 }
 
-// describe() CU:29-135: feature k of a cell with flag byte `fl`, side-table damage `cdmg` and occupants `occ`,
-// seen by a player of team `pteam`.  Returns the raw feature (before the pow map).
-SF_HD inline float obs_feature(const ObsView &v, int k, uint32_t fl, int32_t cdmg, uint32_t occ, int pteam) {
+// describe() CU:29-135 for a cell with flag byte `fl`, side-table damage `cdmg` and occupant word `occ`, seen by a
+// player of team `pteam`: calls emit(k, x) for every feature k whose raw value x (before the pow map) can be
+// non-zero; every feature not emitted is 0.  (A visitor instead of a 32-float array keeps the device kernel's
+// register count low; most cells emit 3 features, most window cells none.)
+template <class F>
+SF_HD inline void obs_cell_emit(const ObsView &v, uint32_t fl, int32_t cdmg, uint32_t occ, int pteam, F &&emit) {
   const int h = (int)(occ & 255u) - 1, z = (int)((occ >> 8) & 255u) - 1, b = (int)(occ >> 16) - 1;
   const bool s0 = h >= 0, s1 = z >= 0, s2 = b >= 0;
   const bool s3 = fl & SF_CELL_WALL, s4 = fl & SF_CELL_CHEST, s5 = fl & SF_CELL_PIN_UP, s6 = fl & SF_CELL_PIN_DN,
              s7 = fl & SF_CELL_POUT, s10 = fl & SF_CELL_TEMP;
-  const bool blocked = s3 || s5 || s6 || s0 || s1;
-  switch (k) {
-    case 0: return (float)(s0 || s1);
-    case 1: return (float)s2;
-    case 2: return (float)s3;
-    case 3: return (float)s4;
-    case 4: return (float)(s5 || s6);
-    case 5: return (float)s7;
-    case 6: return (float)s10;
-    case 7: case 8: case 9: {
-      if (!s0) return 0.f;
-      const int t = (int)((v.hum(HW_FLAGS, h) >> HF_TEAM_SH) & 255u);
-      const int cls = !t ? 2 : (t == pteam ? 0 : 1);
-      return cls == k - 7 ? 1.f : 0.f;
-    }
-    case 10: return (float)s1;
-    case 11: return s0 ? (float)(int32_t)v.hum(HW_KILLS, h) : 0.f;
-    case 12: return s0 ? (float)(int32_t)(v.hum(HW_BPK, h) & 255u) : 0.f;
-    case 13: return s0 ? (float)(int32_t)((v.hum(HW_BPK, h) >> 8) & 255u) : 0.f;
-    case 14: return s0 ? (float)(((v.hum(HW_BPK, h) >> 16) & 255u) != 0u) : 0.f;
-    case 15: return (blocked || s7) ? 1.f : 0.f;
-    case 16: return blocked ? 1.f : 0.f;
-    case 17: return blocked ? (float)(s10 || s0 || s1) : 0.f;
-    case 18: {
-      if (!blocked) return 0.f;
-      if (s0) return (float)((int32_t)v.hum(HW_HP, h) / 1000.0);
-      if (s1) return (float)((int32_t)v.zom(ZW_HP, z) / 1000.0);
-      if (s10) return s3 ? (float)((1100 - cdmg) / 1000.0) : (float)((1000 - cdmg) / 1000.0);
-      return 0.f;
-    }
-    case 19: return (!s0 && !s1 && s2) ? 1.f : 0.f;
-    case 20: case 21: case 22: case 23: {
-      const int i = k - 20;
-      if (s0) return ((int)(v.hum(HW_FLAGS, h) & HF_WAY_MASK) - 1 == i) ? 1.f : 0.f;
-      if (s1) return (float)0.01;
-      if (s2) {
-        const uint32_t ba = v.bul(BW_A, b), bc = v.bul(BW_C, b);
-        if ((int)((ba >> BA_WAY_SH) & 3u) != i) return 0.f;
-        return (float)(((int)(bc & 0xffffu) - (int)(bc >> 16)) / 100.0);
-      }
-      return 0.f;
-    }
-    case 24: case 25: {
-      if (s0) {
-        const uint32_t hf = v.hum(HW_FLAGS, h);
-        int v0, v1;
-        obs_damage_effect(v.tab->der[(hf & HF_PROF) ? 1 : 0], hf, (int32_t)v.hum(HW_STAMINA, h),
-                          (int32_t)v.hum(HW_MINDAMAGE, h), v0, v1);
-        return k == 24 ? (float)(v0 / 1000.0) : (float)(-v1 / 1000.0);
-      }
-      if (s1) return k == 24 ? (float)((int32_t)v.zom(ZW_MINDAMAGE, z) / 1000.0) : 0.f;
-      if (s2)
-        return k == 24 ? (float)((int32_t)v.bul(BW_DAMAGE, b) / 1000.0)
-                       : (float)(-(int32_t)(int16_t)(v.bul(BW_B, b) & 0xffffu) / 1000.0);
-      if (s7) return k == 24 ? (float)(20 / 1000.0) : (float)(10 / 1000.0);
-      return 0.f;
-    }
-    case 26: return s0 ? (float)((int32_t)v.hum(HW_STAMINA, h) / 1000.0) : 0.f;
-    case 27: case 28: case 29: {
-      if (!s4) return 0.f;
-      const int32_t *c = v.tab->cons_items[(fl >> SF_CELL_CONS_SHIFT) & 3u];
-      return (float)((k == 27 ? c[0] : k == 28 ? c[2] : c[1]) / 1000.0);
-    }
-    case 30: return s0 ? (float)((int32_t)v.hum(HW_DAMAGE, h) / 1000.0) : 0.f;
-    case 31: return s0 ? (float)(-(int32_t)v.hum(HW_EFFECT, h) / 1000.0) : 0.f;
+  if (s0 || s1) emit(0, 1.f);
+  if (s2) emit(1, 1.f);
+  if (s3) emit(2, 1.f);
+  if (s4) emit(3, 1.f);
+  if (s5 || s6) emit(4, 1.f);
+  if (s7) emit(5, 1.f);
+  if (s10) emit(6, 1.f);
+  if (s1) emit(10, 1.f);
+  if (s3 || s5 || s6 || s0 || s1) {
+    emit(15, 1.f), emit(16, 1.f);
+    if (s10 || s0 || s1) emit(17, 1.f);
+    if (s0)
+      emit(18, (float)((int32_t)v.hum(HW_HP, h) / 1000.0));
+    else if (s1)
+      emit(18, (float)((int32_t)v.zom(ZW_HP, z) / 1000.0));
+    else if (s10)
+      emit(18, s3 ? (float)((1100 - cdmg) / 1000.0) : (float)((1000 - cdmg) / 1000.0));
+  } else if (s7)
+    emit(15, 1.f);
+  if (s0) {
+    const uint32_t hf = v.hum(HW_FLAGS, h), hb = v.hum(HW_BPK, h);
+    const int t = (int)((hf >> HF_TEAM_SH) & 255u);
+    emit(!t ? 9 : (t == pteam ? 7 : 8), 1.f);
+    emit(11, (float)(int32_t)v.hum(HW_KILLS, h));
+    emit(12, (float)(int32_t)(hb & 255u));
+    emit(13, (float)(int32_t)((hb >> 8) & 255u));
+    emit(14, (float)(((hb >> 16) & 255u) != 0u));
+    emit(20 + (int)(hf & HF_WAY_MASK) - 1, 1.f);
+    int v0, v1;
+    obs_damage_effect(v.tab->der[(hf & HF_PROF) ? 1 : 0], hf, (int32_t)v.hum(HW_STAMINA, h),
+                      (int32_t)v.hum(HW_MINDAMAGE, h), v0, v1);
+    emit(24, (float)(v0 / 1000.0)), emit(25, (float)(-v1 / 1000.0));
+    emit(26, (float)((int32_t)v.hum(HW_STAMINA, h) / 1000.0));
+    emit(30, (float)((int32_t)v.hum(HW_DAMAGE, h) / 1000.0));
+    emit(31, (float)(-(int32_t)v.hum(HW_EFFECT, h) / 1000.0));
+  } else if (s1) {
+    for (int k = 20; k < 24; ++k) emit(k, (float)0.01);
+    emit(24, (float)((int32_t)v.zom(ZW_MINDAMAGE, z) / 1000.0));
+  } else if (s2) {
+    const uint32_t ba = v.bul(BW_A, b), bc = v.bul(BW_C, b);
+    emit(19, 1.f);
+    emit(20 + (int)((ba >> BA_WAY_SH) & 3u), (float)(((int)(bc & 0xffffu) - (int)(bc >> 16)) / 100.0));
+    emit(24, (float)((int32_t)v.bul(BW_DAMAGE, b) / 1000.0));
+    emit(25, (float)(-(int32_t)(int16_t)(v.bul(BW_B, b) & 0xffffu) / 1000.0));
+  } else if (s7) {
+    emit(24, (float)(20 / 1000.0)), emit(25, (float)(10 / 1000.0));
   }
-  return 0.f;
+  if (s4) {
+    const int32_t *c = v.tab->cons_items[(fl >> SF_CELL_CONS_SHIFT) & 3u];
+    emit(27, (float)(c[0] / 1000.0)), emit(28, (float)(c[2] / 1000.0)), emit(29, (float)(c[1] / 1000.0));
+  }
 }
 
 // CU:157: obs.push_back(std::pow(std::abs(x) / 10, 0.2)) — float abs, float / int, double pow, narrowed to float
@@ -139,6 +126,22 @@ SF_HD inline float obs_map(float x) {
   if (x == 0.f) return 0.f;
   const float y = fabsf(x) / 10;
   return (float)pow((double)y, 0.2);
+}
+
+// The handful of raw values that make up almost every non-zero feature (1.0 flags, the 0.01 zombie facing, the
+// portal-exit and chest constants) are mapped through a table the host fills with obs_map() itself, so on the
+// device they cost a few compares instead of a double-precision pow.  Returns false for any other value.
+SF_HD inline bool obs_map_fast(const Tables &t, float x, float &y) {
+  if (x == 0.f) {
+    y = 0.f;
+    return true;
+  }
+  for (int i = 0; i < t.obs_n; ++i)
+    if (x == t.obs_in[i]) {
+      y = t.obs_out[i];
+      return true;
+    }
+  return false;
 }
 
 }  // namespace sf

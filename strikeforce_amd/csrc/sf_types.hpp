@@ -76,6 +76,8 @@ struct Tables {
   Derived der[2];
   int32_t cons_items[4][3];  // stamina, Hp, effect
   int32_t teams[16];         // BATTLE mode team of agent i
+  int32_t obs_n;             // observation fast map: obs_out[i] = obs_map(obs_in[i]), filled on the host
+  float obs_in[16], obs_out[16];
 };
 
 // ---- everything a kernel needs -----------------------------------------------------------------------

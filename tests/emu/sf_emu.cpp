@@ -66,7 +66,12 @@ static void run_observe(const Params &p, float *out) {
           fl = p.flags[(size_t)a * p.cells_pad + ci];
           if (fl & SF_CELL_TEMP) cdmg = p.aux_dmg[(size_t)a * p.cells + ci];
         }
-        for (int k = 0; k < SF_OBS_CHANNELS; ++k) o[k * W2 + w] = obs_map(obs_feature(v, k, fl, cdmg, occ[w], pteam));
+        for (int k = 0; k < SF_OBS_CHANNELS; ++k) o[k * W2 + w] = 0.f;
+        obs_cell_emit(v, fl, cdmg, occ[w], pteam, [&](int k, float x) {
+          float y;
+          if (!obs_map_fast(*p.tab, x, y)) y = obs_map(x);
+          o[k * W2 + w] = y;
+        });
       }
     }
 }
