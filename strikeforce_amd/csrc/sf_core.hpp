@@ -40,6 +40,10 @@ struct Core {
     V ppos;
     // RNG (lane < 18): log_3(random[i]) (bit 16 set: random[i] == 0), us[i], seed[i]  RN:31
     V rl, rus, rseed;
+    // the NEXT episode's generator, warmed up a few draws per step so that an in-kernel restart does not stall on
+    // _srand's 1024 serial draws (RN:73-74): log state, seed digits, draws done so far (0..1024)
+    V rl2, rseed2;
+    uint32_t warm;
     // wave-uniform scalars  G:461
     int32_t frame, kills, tkills, loot, chests, steps, episodes, done, outcome, ended;
     uint32_t jomle, draws;
@@ -82,31 +86,44 @@ struct Core {
   // SQ_INSTS_SALU ~ SQ_INSTS_VALU, one scalar issue per cycle per CU), so the wave-uniform tail of a draw
   // (mod, log lookup, power) is deliberately computed on the vector unit, redundantly in every lane, and only the
   // 10-bit result goes back to an SGPR.
-  static SF_DEV uint32_t draw(Arena &S, const uint8_t *lds, const Params &p) {  // RN:54-62
-    const P tap = W::ltu(W::lane(), 18u) & ((S.rl & RL_ZERO) == 0u);
-    const V pw = pow3_v(lds, p, (S.rl * S.rseed) & 0xffffu, tap);  // p[random[i]][seed[i]] = random[i]^seed[i]
-    const V sum = W::vec(W::sum18(W::select(tap, S.rus * pw, V(0u))) + 1u);  // < 2^24, same in every lane
+  template <bool WANT_OUT>
+  static SF_DEV V draw_core(V &rl, const V &rus, const V &rseed, uint32_t &jomle, const uint8_t *lds, const Params &p) {
+    const P tap = W::ltu(W::lane(), 18u) & ((rl & RL_ZERO) == 0u);
+    const V pw = pow3_v(lds, p, (rl * rseed) & 0xffffu, tap);  // p[random[i]][seed[i]] = random[i]^seed[i]
+    const V sum = W::vec(W::sum18(W::select(tap, rus * pw, V(0u))) + 1u);  // < 2^24, same in every lane
     V t = (sum & 0xffffu) - (sum >> 16);
     t = t + (W::sar31(t) & 65537u);
     t = W::select(t == 0u, V(1u), t);  // binpow(sum + (int)(sum == 0), ...)
-    S.jomle += 1u;
-    const uint32_t e = S.jomle & 0xffffu;  // b %= mod - 1
+    jomle += 1u;
+    const uint32_t e = jomle & 0xffffu;  // b %= mod - 1
     const V lnew = (W::gload_u16(p.logt, t - 1u, W::all()) * e) & 0xffffu;
-    S.rl = W::select(W::lane() == 17u, lnew, W::shl1(S.rl));  // the 17 swaps: rotate left, new value last
+    rl = W::select(W::lane() == 17u, lnew, W::shl1(rl));  // the 17 swaps: rotate left, new value last
+    if (WANT_OUT) return pow3_v(lds, p, lnew, W::all()) & 1023u;
+    return V(0u);
+  }
+  static SF_DEV uint32_t draw(Arena &S, const uint8_t *lds, const Params &p) {  // RN:54-62
     S.draws += 1u;
-    return W::first(pow3_v(lds, p, lnew, W::all()) & 1023u);
+    return W::first(draw_core<true>(S.rl, S.rus, S.rseed, S.jomle, lds, p));
   }
 
-  static SF_DEV void srand_(Arena &S, const uint8_t *lds, const Params &p, uint64_t tb, uint64_t us) {  // RN:64-76
-    S.rl = V(RL_ZERO), S.rus = V(0u), S.rseed = V(0u);
+  static SF_DEV void seed_digits(V &digits, uint64_t x) {  // RN:65-68: decimal digit i of x, plus one, on lane i
+    digits = V(0u);
     for (int i = 0; i < 18; ++i) {
-      W::setlane(S.rus, (uint32_t)i, (uint32_t)(us % 10u) + 1u);
-      W::setlane(S.rseed, (uint32_t)i, (uint32_t)(tb % 10u) + 1u);
-      us /= 10u;
-      tb /= 10u;
+      W::setlane(digits, (uint32_t)i, (uint32_t)(x % 10u) + 1u);
+      x /= 10u;
     }
+  }
+  static SF_DEV void srand_(Arena &S, const uint8_t *lds, const Params &p, uint64_t tb, uint64_t us) {  // RN:64-76
+    S.rl = V(RL_ZERO);
+    seed_digits(S.rus, us);
+    seed_digits(S.rseed, tb);
     S.jomle = 18u;
-    for (int i = 0; i < 1024; ++i) draw(S, lds, p);
+    for (int i = 0; i < 1024; ++i) draw_core<false>(S.rl, S.rus, S.rseed, S.jomle, lds, p);
+  }
+  // advance the next episode's warm-up by up to n draws
+  static SF_DEV void prewarm(Arena &S, const uint8_t *lds, const Params &p, uint32_t n) {
+    uint32_t j2 = 18u + S.warm;
+    for (; n && S.warm < 1024u; --n, ++S.warm) draw_core<false>(S.rl2, S.rus, S.rseed2, j2, lds, p);
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -885,7 +902,8 @@ struct Core {
 
   // ------------------------------------------------------------------------------------------------
   // setup() G:1231-1277 + load_data() G:1741-1925 for this arena, then the first loop top.
-  static SF_DEV void reset(Arena &S, uint8_t *lds, const Params &p, int a, uint64_t tb, uint64_t serial) {
+  // `adopt`: the generator state for this seed was already warmed up in S.rl2 (see prewarm)
+  static SF_DEV void reset(Arena &S, uint8_t *lds, const Params &p, int a, uint64_t tb, uint64_t serial, bool adopt) {
     S.frame = S.kills = S.tkills = S.loot = S.chests = S.steps = 0;
     S.done = 0, S.outcome = SF_RUNNING;
     S.draws = 0u;
@@ -899,7 +917,17 @@ struct Core {
     S.ppos = W::gload(p.map_exits, W::lane(), W::ltu(W::lane(), (uint32_t)p.P));
     W::copy_g2l(lds, p.map_flags, (uint32_t)p.cells_pad);
     S.dirty = 1u;
-    srand_(S, lds, p, tb, serial);
+    if (adopt) {
+      prewarm(S, lds, p, 1024u);  // whatever is still missing
+      S.rl = S.rl2, S.rseed = S.rseed2, S.jomle = 18u + 1024u;
+    } else {
+      srand_(S, lds, p, tb, serial);
+    }
+    if (p.auto_reset) {  // arm the warm-up of the episode after this one
+      seed_digits(S.rseed2, tb + (uint64_t)(uint32_t)p.reseed);
+      S.rl2 = V(RL_ZERO);
+      S.warm = 0u;
+    }
     if (p.mode == SF_MODE_BATTLE) {  // G:1846-1859
       for (int i = 0; i < p.n_agents; ++i)
         human_make(S, p, (uint32_t)i, 0, POS_NONE, 1, p.tab->teams[i], HF_CTRL | (i ? HF_REMOTE : 0u));
@@ -946,6 +974,7 @@ struct Core {
     ++S.frame;
     update_bull(S, lds, p);
     ++S.steps;
+    if (p.auto_reset) prewarm(S, lds, p, 4u);
     loop_top(S, lds, p, a);
     if (S.done) {
       S.ended = 1;
@@ -956,7 +985,7 @@ struct Core {
         // inlined on purpose: an out-of-line call gives the kernel a stack, and scratch-backed launches
         // measured 10 % slower at K = 50 and 2x slower at K = 1 on MI355X
         const int32_t ep = S.episodes;
-        reset(S, lds, p, a, tb, sr);
+        reset(S, lds, p, a, tb, sr, true);
         S.episodes = ep;
         S.ended = 1;
       }
@@ -1003,6 +1032,8 @@ struct Core {
       S.rus = (rw >> 20) & 15u, S.rseed = (rw >> 24) & 15u;
       const P nz = in & (val != 0u);
       S.rl = W::select(nz, W::gload_u16(p.logt, val - 1u, nz), V(RL_ZERO));
+      const V rw2 = W::gload(p.rng2 + (size_t)a * RNG_WORDS, ln, in);  // log form: never dumped
+      S.rl2 = rw2 & 0x1ffffu, S.rseed2 = rw2 >> 24;
     }
     const V sc = W::gload((const uint32_t *)p.scal + (size_t)a * SC_WORDS, ln, W::ltu(ln, (uint32_t)SC_WORDS));
     S.frame = (int32_t)W::readlane(sc, SC_FRAME), S.kills = (int32_t)W::readlane(sc, SC_KILLS);
@@ -1014,6 +1045,7 @@ struct Core {
     S.tb_lo = W::readlane(sc, SC_TB_LO), S.tb_hi = W::readlane(sc, SC_TB_HI);
     S.sr_lo = W::readlane(sc, SC_SR_LO), S.sr_hi = W::readlane(sc, SC_SR_HI);
     S.draws = W::readlane(sc, SC_DRAWS);
+    S.warm = W::readlane(sc, SC_WARM);
     W::copy_g2l(lds, p.flags + (size_t)a * (size_t)p.cells_pad, (uint32_t)p.cells_pad);
     S.dirty = 0u;
   }
@@ -1051,6 +1083,7 @@ struct Core {
       const P in = W::ltu(ln, 18u), nz = in & ((S.rl & RL_ZERO) == 0u);
       const V val = W::select(nz, pow3_v(lds, p, S.rl & 0xffffu, nz), V(0u));
       W::gstore(p.rng + (size_t)a * RNG_WORDS, ln, val | (S.rus << 20) | (S.rseed << 24), in);
+      W::gstore(p.rng2 + (size_t)a * RNG_WORDS, ln, (S.rl2 & 0x1ffffu) | (S.rseed2 << 24), in);
     }
     V sc = V(0u);
     W::setlane(sc, SC_FRAME, (uint32_t)S.frame), W::setlane(sc, SC_KILLS, (uint32_t)S.kills);
@@ -1062,6 +1095,7 @@ struct Core {
     W::setlane(sc, SC_TB_LO, S.tb_lo), W::setlane(sc, SC_TB_HI, S.tb_hi);
     W::setlane(sc, SC_SR_LO, S.sr_lo), W::setlane(sc, SC_SR_HI, S.sr_hi);
     W::setlane(sc, SC_DRAWS, S.draws);
+    W::setlane(sc, SC_WARM, S.warm);
     W::gstore((uint32_t *)p.scal + (size_t)a * SC_WORDS, ln, sc, W::ltu(ln, (uint32_t)SC_WORDS));
     if (S.dirty) W::copy_l2g(p.flags + (size_t)a * (size_t)p.cells_pad, lds, (uint32_t)p.cells_pad);
   }
@@ -1072,7 +1106,8 @@ struct Core {
     Arena S;
     S.episodes = 0, S.ended = 0;
     W::copy_g2l(lds + p.cells_pad, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
-    reset(S, lds, p, a, tb[a], serial[a]);
+    S.rl2 = V(RL_ZERO), S.rseed2 = V(0u), S.warm = 0u;
+    reset(S, lds, p, a, tb[a], serial[a], false);
     store(S, lds, p, a);
   }
 

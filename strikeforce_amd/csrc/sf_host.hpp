@@ -260,7 +260,7 @@ struct Env {
     if ((rc = alloc(d_params, 1)) || (rc = alloc(d_logt, 65536)) || (rc = alloc(d_exptab, 512)) || (rc = alloc(d_tab, 1)) || (rc = alloc(d_map_flags, (size_t)p.cells_pad)) || (rc = alloc(d_map_pidx, (size_t)cells)) ||
         (rc = alloc(d_map_exits, (size_t)p.P)) || (rc = alloc(p.hum, HW_WORDS * A * p.H)) ||
         (rc = alloc(p.zom, ZW_WORDS * A * p.Z)) || (rc = alloc(p.bul, BW_WORDS * A * p.B)) ||
-        (rc = alloc(p.por, A * p.P)) || (rc = alloc(p.rng, A * RNG_WORDS)) || (rc = alloc(p.scal, A * SC_WORDS)) ||
+        (rc = alloc(p.por, A * p.P)) || (rc = alloc(p.rng, A * RNG_WORDS)) || (rc = alloc(p.rng2, A * RNG_WORDS)) || (rc = alloc(p.scal, A * SC_WORDS)) ||
         (rc = alloc(p.results, A * p.n_agents * 8)) || (rc = alloc(p.flags, A * (size_t)p.cells_pad)) ||
         (rc = alloc(p.aux_dmg, A * (size_t)cells)) || (rc = alloc(p.aux_pidx, A * (size_t)cells)) ||
         (rc = alloc(d_tb, A)) || (rc = alloc(d_serial, A)) || (rc = alloc(d_cmd, A * p.n_agents)))
@@ -282,7 +282,7 @@ struct Env {
   }
 
   void destroy() {
-    void *ptrs[] = {d_params, d_logt, d_exptab, d_tab, d_map_flags, d_map_pidx, d_map_exits, p.hum, p.zom, p.bul, p.por, p.rng, p.scal, p.results,
+    void *ptrs[] = {d_params, d_logt, d_exptab, d_tab, d_map_flags, d_map_pidx, d_map_exits, p.hum, p.zom, p.bul, p.por, p.rng, p.rng2, p.scal, p.results,
                     p.flags, p.aux_dmg, p.aux_pidx, d_tb, d_serial, d_cmd, d_obs};
     for (void *q : ptrs)
       if (q) rt.free(q);

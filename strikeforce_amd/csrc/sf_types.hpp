@@ -57,7 +57,7 @@ constexpr uint32_t PF_ACTIVE = 1u << 31;
 
 // ---- per-arena scalar block: 24 dwords ----------------------------------------------------------------
 enum { SC_FRAME = 0, SC_KILLS, SC_TKILLS, SC_LOOT, SC_CHESTS, SC_JOMLE, SC_STEPS, SC_EPISODES, SC_DONE, SC_OUTCOME,
-       SC_ENDED, SC_TB_LO, SC_TB_HI, SC_SR_LO, SC_SR_HI, SC_DRAWS, SC_WORDS = 24 };
+       SC_ENDED, SC_TB_LO, SC_TB_HI, SC_SR_LO, SC_SR_HI, SC_DRAWS, SC_WARM, SC_WORDS = 24 };
 constexpr int RNG_WORDS = 18;
 
 // ---- derived per-profile tables (Human::build, Character.hpp:650-709) ---------------------------------
@@ -91,6 +91,7 @@ struct Params {
   uint32_t *bul;   // [BW_WORDS][A][B]
   uint32_t *por;   // [A][P]
   uint32_t *rng;   // [A][RNG_WORDS]
+  uint32_t *rng2;  // [A][RNG_WORDS]  the next episode's generator being warmed up (log form)
   int32_t *scal;   // [A][SC_WORDS]
   int32_t *results;// [A][n_agents][8]
   uint8_t *flags;  // [A][cells_pad]
