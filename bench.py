@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--arenas", type=int, default=4096, help="arenas per GPU")
     ap.add_argument("--k-per-launch", type=int, default=50, help="loop iterations per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-interactive", action="store_true", help="skip the K=1 + observation measurement")
     args = ap.parse_args()
 
     import torch
@@ -137,26 +138,28 @@ def main():
     k_ms, k_launches = g.kernel_time(False)
 
     # the interactive loop an RL learner runs: one launch per step (K = 1) + the observation of every agent
-    obs_n = 40
-    d_obs = torch.empty(args.arenas * cfg.n_agents * 30752, dtype=torch.float32, device="cuda")
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    g.observe_device(d_obs.data_ptr())
-    torch.cuda.synchronize()
-    ev[0].record()
-    for s in range(obs_n):
-        g.step_device(d_cmds.data_ptr() + (s % total) * stride, 1)
+    obs_n = 0 if args.no_interactive else 40
+    loop_ms = obs_ms = k1_ms = 0.0
+    if obs_n:
+        d_obs = torch.empty(args.arenas * cfg.n_agents * 30752, dtype=torch.float32, device="cuda")
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         g.observe_device(d_obs.data_ptr())
-    ev[1].record()
-    for s in range(obs_n):
-        g.observe_device(d_obs.data_ptr())
-    ev[2].record()
-    for s in range(obs_n):
-        g.step_device(d_cmds.data_ptr() + (s % total) * stride, 1)
-    ev[3].record()
-    torch.cuda.synchronize()
-    loop_ms = ev[0].elapsed_time(ev[1]) / obs_n
-    obs_ms = ev[1].elapsed_time(ev[2]) / obs_n
-    k1_ms = ev[2].elapsed_time(ev[3]) / obs_n
+        torch.cuda.synchronize()
+        ev[0].record()
+        for s in range(obs_n):
+            g.step_device(d_cmds.data_ptr() + (s % total) * stride, 1)
+            g.observe_device(d_obs.data_ptr())
+        ev[1].record()
+        for s in range(obs_n):
+            g.observe_device(d_obs.data_ptr())
+        ev[2].record()
+        for s in range(obs_n):
+            g.step_device(d_cmds.data_ptr() + (s % total) * stride, 1)
+        ev[3].record()
+        torch.cuda.synchronize()
+        loop_ms = ev[0].elapsed_time(ev[1]) / obs_n
+        obs_ms = ev[1].elapsed_time(ev[2]) / obs_n
+        k1_ms = ev[2].elapsed_time(ev[3]) / obs_n
     g.kernel_time(False)
 
     if world > 1:
@@ -195,14 +198,15 @@ def main():
                          "algorithmic_bytes_per_arena_step": bytes_step},
         }
         obs_bytes = args.arenas * cfg.n_agents * (30752 * 4 + 961 * 8)
-        out["interactive"] = {
-            "what": "per rank: K=1 launch per step + sf_observe_device for every agent, %d steps" % obs_n,
-            "env_steps_per_s": world * args.arenas / (loop_ms / 1e3),
-            "ms_per_step": loop_ms, "k_step_K1_ms": k1_ms, "k_observe_ms": obs_ms,
-            "k_observe_roofline": {"bound": "hbm", "achieved": obs_bytes / (obs_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": obs_bytes / (obs_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                   "algorithmic_bytes_per_agent_step": 30752 * 4 + 961 * 8},
-        }
+        if obs_n:
+            out["interactive"] = {
+              "what": "per rank: K=1 launch per step + sf_observe_device for every agent, %d steps" % obs_n,
+              "env_steps_per_s": world * args.arenas / (loop_ms / 1e3),
+              "ms_per_step": loop_ms, "k_step_K1_ms": k1_ms, "k_observe_ms": obs_ms,
+              "k_observe_roofline": {"bound": "hbm", "achieved": obs_bytes / (obs_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": obs_bytes / (obs_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                     "algorithmic_bytes_per_agent_step": 30752 * 4 + 961 * 8},
+          }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
