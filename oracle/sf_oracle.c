@@ -32,6 +32,20 @@ enum { S_HUMAN = 0, S_ZOMBIE = 1, S_BULLET = 2, S_WALL = 3, S_CHEST = 4, S_PIN_U
 static const int wdx[4] = {1, 0, -1, 0}, wdy[4] = {0, 1, 0, -1}; /* CH:47, G:459 */
 enum { LIM_PORTAL = 1000, LIM_BLOCK = 1100 };                   /* G:37 */
 
+/* branch-coverage counters (test aid: tests assert that the parity runs really exercise these paths) */
+enum { EV_ZOMBIE_PUNCH, EV_ZOMBIE_MOVE, EV_ZOMBIE_BLOCKED, EV_HUMAN_HIT, EV_ZOMBIE_HIT, EV_HUMAN_KILLED, EV_ZOMBIE_KILLED,
+       EV_BLOCK_PLACED, EV_BLOCK_BROKEN, EV_EXIT_PLACED, EV_ENTRANCE_PLACED, EV_PORTAL_BROKEN, EV_TELEPORT,
+       EV_CHEST_SPAWN, EV_CHEST_CLAIM, EV_ZOMBIE_SPAWN, EV_NPC_SPAWN, EV_PUNCH, EV_SHOT, EV_THROW, EV_SHOT_BLOCKED,
+       EV_USE, EV_BULLET_ORPHANED, EV_BULLET_STOPPED, EV_BULLET_EXPIRED, EV_BULLET_ABSORBED, EV_RADIATION,
+       EV_NO_BULLET_SLOT, EV_EPISODE_END, EV_HUMAN_MOVE, EV_HUMAN_MOVE_BLOCKED, EV_COUNT };
+static const char *const EV_NAMES[EV_COUNT] = {
+    "zombie_punch", "zombie_move", "zombie_blocked", "human_hit", "zombie_hit", "human_killed", "zombie_killed",
+    "block_placed", "block_broken", "exit_placed", "entrance_placed", "portal_broken", "teleport", "chest_spawn",
+    "chest_claim", "zombie_spawn", "npc_spawn", "punch", "shot", "throw", "shot_blocked", "use", "bullet_orphaned",
+    "bullet_stopped", "bullet_expired", "bullet_absorbed", "radiation", "no_bullet_slot", "episode_end", "human_move",
+    "human_move_blocked"};
+#define EV(a, k) (++(a)->ev[k])
+
 typedef struct {
   uint16_t s;
   int dmg, portal_ind;
@@ -78,6 +92,7 @@ typedef struct {
   int done, outcome, ended_last_step;
   int32_t results[SF_MAX_AGENTS][8];
   long long draws; /* number of _rand() calls since reset (test aid) */
+  long long ev[EV_COUNT];
 } oarena;
 
 typedef struct sfo_env {
@@ -284,6 +299,7 @@ static void o_claim_chest(sfo_env *e, oarena *a, ohuman *pl) {
     pl->mindamage += c[2];
     SSET(n, S_CHEST, 0);
     --a->chest;
+    EV(a, EV_CHEST_CLAIM);
   }
 }
 
@@ -300,6 +316,7 @@ static void o_teleport(sfo_env *e, oarena *a, int hi) {
   t->human = hi;
   SSET(n, S_HUMAN, 0);
   pl->f = p->f, pl->r = p->r, pl->c = p->c;
+  EV(a, EV_TELEPORT);
 }
 
 /* G:532-543 */
@@ -311,6 +328,7 @@ static void o_spawn_chest(sfo_env *e, oarena *a) {
   n->cons = o_rand(a) % 4;
   SSET(n, S_CHEST, 1);
   ++a->chest;
+  EV(a, EV_CHEST_SPAWN);
 }
 
 /* G:545-558 */
@@ -329,6 +347,7 @@ static void o_spawn_zombie_npc(sfo_env *e, oarena *a) {
   n->zombie = index;
   SSET(n, S_ZOMBIE, 1);
   z->alive = 1;
+  EV(a, EV_ZOMBIE_SPAWN);
 }
 
 /* G:560-572 */
@@ -343,6 +362,7 @@ static void o_spawn_human_npc(sfo_env *e, oarena *a) {
   SSET(n, S_HUMAN, 1);
   a->hum[index].remote = 0;
   a->hum[index].alive = 1;
+  EV(a, EV_NPC_SPAWN);
 }
 
 /* G:574-598 */
@@ -358,8 +378,10 @@ static void o_zombie_damage(sfo_env *e, oarena *a, onode *pix) {
     owner->effect += b->effect;
   }
   b->alive = 0;
+  EV(a, EV_ZOMBIE_HIT);
   if (z->hp <= 0) {
     z->alive = 0;
+    EV(a, EV_ZOMBIE_KILLED);
     SSET(pix, S_ZOMBIE, 0);
     if (owner && owner->team == a->hum[e->ind].team) {
       int pts = 500 + 250 * z->super_;
@@ -393,8 +415,10 @@ static void o_human_damage(sfo_env *e, oarena *a, onode *pix) {
     owner->effect += b->effect;
   }
   b->alive = 0;
+  EV(a, EV_HUMAN_HIT);
   if (h->hp <= 0) {
     h->alive = 0;
+    EV(a, EV_HUMAN_KILLED);
     SSET(pix, S_HUMAN, me == h);
     if (owner && owner->team == me->team && h->team != me->team) {
       ++a->teams_kills, a->loot += 100;
@@ -439,7 +463,9 @@ static void o_zombie_action(sfo_env *e, oarena *a) {
             pix->bullet = index;
             SSET(pix, S_BULLET, 1);
             a->bull[index].alive = 1;
-          }
+            EV(a, EV_ZOMBIE_PUNCH);
+          } else if (index == -1)
+            EV(a, EV_NO_BULLET_SLOT);
           b = 1;
         }
       }
@@ -454,8 +480,10 @@ static void o_zombie_action(sfo_env *e, oarena *a) {
             t->zombie = _;
             SSET(own, S_ZOMBIE, 0);
             z->r = wdx[i2] + j, z->c = wdy[i2] + k;
+            EV(a, EV_ZOMBIE_MOVE);
             break;
-          }
+          } else
+            EV(a, EV_ZOMBIE_BLOCKED);
         }
       }
     }
@@ -531,6 +559,7 @@ static void o_obey(sfo_env *e, oarena *a, char c, int hi) {
         SSET(n, S_WALL, 1);
         --pl->blocks;
         a->temp[a->ntemp++] = ci;
+        EV(a, EV_BLOCK_PLACED);
       }
       return;
     } else {
@@ -540,6 +569,7 @@ static void o_obey(sfo_env *e, oarena *a, char c, int hi) {
         n->portal_ind = pl->portal_ind;
         pl->portal_ind = -1;
         a->temp[a->ntemp++] = ci;
+        EV(a, EV_ENTRANCE_PLACED);
       } else if (pl->portals) {
         int index = o_p_ind(e, a);
         if (index == -1) return;
@@ -550,6 +580,7 @@ static void o_obey(sfo_env *e, oarena *a, char c, int hi) {
         a->portal[index].f = pl->f, a->portal[index].r = r, a->portal[index].c = cc;
         a->portal[index].active = 1;
         a->temp[a->ntemp++] = ci;
+        EV(a, EV_EXIT_PLACED);
       }
       return;
     }
@@ -572,7 +603,9 @@ static void o_obey(sfo_env *e, oarena *a, char c, int hi) {
       t->human = hi;
       SSET(&a->map[cell_of(e, pl->f, pl->r, pl->c)], S_HUMAN, 0);
       pl->r = r, pl->c = cc;
-    }
+      EV(a, EV_HUMAN_MOVE);
+    } else
+      EV(a, EV_HUMAN_MOVE_BLOCKED);
     return;
   }
   if ((i = idx_in("fghj", 4, c)) >= 0) {
@@ -591,6 +624,7 @@ static void o_obey(sfo_env *e, oarena *a, char c, int hi) {
     return;
   }
   if (c == 'u') {
+    if (pl->vec == 0 && pl->cons[pl->ind] >= 1) EV(a, EV_USE);
     o_use(e, pl);
     return;
   }
@@ -598,8 +632,10 @@ static void o_obey(sfo_env *e, oarena *a, char c, int hi) {
     int bway = pl->way - 1;
     int r = pl->r + wdx[bway], cc = pl->c + wdy[bway];
     int index = o_b_ind(e, a);
+    if (index == -1) EV(a, EV_NO_BULLET_SLOT);
     if (index == -1 || r >= e->N || 0 > r || cc >= e->M || 0 > cc) return;
     int can;
+    const int kind = c == 'z' ? EV_PUNCH : (pl->vec == 1 ? EV_THROW : EV_SHOT);
     if (c == 'z')
       can = o_punch(e, a, hi, &a->bull[index]);
     else if (pl->vec == 1)
@@ -611,10 +647,13 @@ static void o_obey(sfo_env *e, oarena *a, char c, int hi) {
     onode *t = &a->map[cell_of(e, pl->f, r, cc)];
     char sit = o_showit(a, t);
     if (can && ((sit != '#' && sit != 'v' && sit != '^') || SB(t, S_TEMP))) {
+      if (SB(t, S_BULLET)) EV(a, EV_BULLET_ORPHANED);
       t->bullet = index;
       SSET(t, S_BULLET, 1);
       a->bull[index].alive = 1;
-    }
+      EV(a, kind);
+    } else if (can)
+      EV(a, EV_SHOT_BLOCKED);
     return;
   }
 }
@@ -687,6 +726,7 @@ static void o_update_bull(sfo_env *e, oarena *a) {
       int dist = abs(b->f - b->df) + abs(b->r - b->dr) + abs(b->c - b->dc); /* Bullet::expire IT:165-168 */
       if (dist + 1 >= b->range) {
         b->alive = 0;
+        EV(a, EV_BULLET_EXPIRED);
         continue;
       }
       int d = b->way - 1;
@@ -694,11 +734,14 @@ static void o_update_bull(sfo_env *e, oarena *a) {
       char sit = o_showit(a, dn);
       if ((sit != '#' && sit != 'v' && sit != '^') || SB(dn, S_TEMP)) {
         onode *d1 = &a->map1[cell_of(e, i, j + wdx[d], k + wdy[d])];
+        if (SB(d1, S_BULLET)) EV(a, EV_BULLET_ORPHANED);
         d1->bullet = _;
         b->r = j + wdx[d], b->c = k + wdy[d];
         SSET(d1, S_BULLET, 1);
-      } else
+      } else {
         b->alive = 0;
+        EV(a, EV_BULLET_STOPPED);
+      }
     }
   for (int _ = 0; _ < cnt; ++_) {
     int ci = a->place[_];
@@ -717,6 +760,8 @@ static void o_portal_damage(sfo_env *e, oarena *a) {
       int index = o_b_ind(e, a);
       if (index == -1) return;
       o_shot(&a->bull[index], p->f, p->r, p->c, 3, 20, -10, 1, 0);
+      if (SB(n, S_BULLET)) EV(a, EV_BULLET_ORPHANED);
+      EV(a, EV_RADIATION);
       n->bullet = index;
       SSET(n, S_BULLET, 1);
       a->bull[index].alive = 1;
@@ -735,6 +780,7 @@ static void o_update_tmp(sfo_env *e, oarena *a) {
       n->dmg += b->damage;
       SSET(n, S_BULLET, 0);
       b->alive = 0;
+      EV(a, EV_BULLET_ABSORBED);
     }
   }
   for (int t = 0; t < a->ntemp; ++t) {
@@ -751,10 +797,12 @@ static void o_update_tmp(sfo_env *e, oarena *a) {
       en->portal_ind = -1;
       en->dmg = 0;
       a->portal[i].active = 0;
+      EV(a, EV_PORTAL_BROKEN);
     } else if (c == '#' && dmg >= LIM_BLOCK) {
       SSET(en, S_WALL, 0);
       SSET(en, S_TEMP, 0);
       en->dmg = 0;
+      EV(a, EV_BLOCK_BROKEN);
     }
   }
   for (int i = 0; i < a->ntemp; ++i)
@@ -941,6 +989,7 @@ static void o_step_arena(sfo_env *e, oarena *a, const uint8_t *ext) {
   if (a->done) {
     a->ended_last_step = 1;
     ++a->episodes;
+    EV(a, EV_EPISODE_END);
     if (e->cfg.auto_reset)
       o_reset_arena(e, a, a->tb + (e->cfg.reseed_stride > 0 ? e->cfg.reseed_stride : e->cfg.arenas), a->serial);
   }
@@ -1340,6 +1389,14 @@ void sfo_kat_rand(uint64_t tb, uint64_t serial, int32_t n, int32_t *out) {
 }
 int32_t sfo_kat_compute_damage(int32_t x, int32_t y) { return o_compute_damage(x, y); }
 int64_t sfo_draws(sfo_env *e, int32_t arena) { return e->ar[arena].draws; }
+int32_t sfo_event_count(void) { return EV_COUNT; }
+const char *sfo_event_name(int32_t k) { return k >= 0 && k < EV_COUNT ? EV_NAMES[k] : ""; }
+/* sum over all arenas, never reset */
+void sfo_events(sfo_env *e, int64_t *out) {
+  for (int k = 0; k < EV_COUNT; ++k) out[k] = 0;
+  for (int i = 0; i < e->cfg.arenas; ++i)
+    for (int k = 0; k < EV_COUNT; ++k) out[k] += e->ar[i].ev[k];
+}
 
 /* cpu_baseline leg of bench.py: run k steps over all arenas with the bench's LCG random agent
  * (x <- 1664525 x + 1013904223, (x >> 16) % 28 over the command set minus '3' and '_'). */

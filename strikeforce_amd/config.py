@@ -76,6 +76,32 @@ def synthetic_map(rows, cols, floors=1, wall_p=0.08, map_seed=2024, portal_pairs
     return "".join(chars).encode("ascii"), portal
 
 
+def three_floor_map(rows, cols, wall_p=0.05, map_seed=7):
+    """Three floors; floor f has one exit 'O' (exit number f in scan order), '^' entrances in its top border that
+    lead to floor (f+1) % 3 and 'v' entrances that lead to floor (f-1) % 3 (cf. map/floor1.txt .. floor3.txt)."""
+    g = _lcg(map_seed)
+    thr = int(wall_p * 65536)
+    chars, portal = [], []
+    for f in range(3):
+        for r in range(rows):
+            for c in range(cols):
+                border = r == 0 or c == 0 or r == rows - 1 or c == cols - 1
+                chars.append("#" if border or next(g) < thr else ".")
+                portal.append(-1)
+    idx = lambda f, r, c: (f * rows + r) * cols + c
+    for f in range(3):
+        for (r, c) in [(1, 1), (3, 1)] + [(1, i + 1) for i in range(1, 10)]:
+            chars[idx(f, r, c)] = "."
+        chars[idx(f, rows // 2, cols // 2 + f)] = "O"
+        for j, (sym, dest) in enumerate((("^", (f + 1) % 3), ("v", (f - 1) % 3))):
+            for dc in range(2):
+                cc = 12 + 5 * j + dc
+                chars[idx(f, 0, cc)] = sym
+                portal[idx(f, 0, cc)] = dest
+                chars[idx(f, 1, cc)] = "."
+    return "".join(chars).encode("ascii"), portal
+
+
 class Workload:
     """Owns the ctypes Config and the buffers it points into."""
 
@@ -142,6 +168,18 @@ def baseline_workload(which, arenas=None, device=0, auto_reset=1):
         cfg = make_config(arenas or 4096, 256, 256, H=8, Z=56, B=128, P=16, mode=abi.MODE_BATTLE, n_agents=8,
                           teams=list(range(1, 9)), device=device, auto_reset=auto_reset)
         m, p = synthetic_map(256, 256, portal_pairs=2)
+    elif which == "MAXCAP":  # every slot pool at the device kernels' maximum (64/64/256/64), 16 commanded humans
+        cfg = make_config(arenas or 2, 48, 48, H=64, Z=64, B=256, P=64, mode=abi.MODE_BATTLE, n_agents=16,
+                          teams=[1 + (i % 3) for i in range(16)], device=device, auto_reset=auto_reset)
+        m, p = synthetic_map(48, 48, wall_p=0.04)
+    elif which == "FLOORS":  # three floors linked by '^' / 'v' entrances like map/floor1-3.txt, Squad start layout
+        cfg = make_config(arenas or 2, 20, 30, floors=3, H=12, Z=10, B=32, P=8, mode=abi.MODE_SQUAD, n_agents=3,
+                          device=device, auto_reset=auto_reset)
+        m, p = three_floor_map(20, 30)
+    elif which == "STRESS":  # not a BASELINE config: tiny slot pools so that every allocator runs dry
+        cfg = make_config(arenas or 8, 24, 40, H=6, Z=12, B=5, P=3, chests=6, mode=abi.MODE_TIMER, device=device,
+                          auto_reset=auto_reset, timer_frames=600)
+        m, p = synthetic_map(24, 40, wall_p=0.05, portal_pairs=1)
     else:
         raise ValueError(which)
     return Workload(which, cfg, m, p)

@@ -30,6 +30,10 @@ def lib():
         L.sfo_draws.restype = C.c_int64
         L.sfo_bench_run.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]
         L.sfo_bench_run.restype = C.c_int64
+        L.sfo_event_count.restype = C.c_int32
+        L.sfo_event_name.argtypes = [C.c_int32]
+        L.sfo_event_name.restype = C.c_char_p
+        L.sfo_events.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         _LIB = L
     return _LIB
 
@@ -144,3 +148,10 @@ class Oracle:
 
     def draws(self, arena):
         return self.L.sfo_draws(self.h, arena)
+
+    def events(self):
+        """Branch-coverage counters summed over all arenas: {name: count}."""
+        n = self.L.sfo_event_count()
+        out = (C.c_int64 * n)()
+        self.L.sfo_events(self.h, out)
+        return {self.L.sfo_event_name(k).decode(): out[k] for k in range(n)}

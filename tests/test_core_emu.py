@@ -28,7 +28,8 @@ def _lockstep(name, arenas, steps, check_every=1, **kw):
     return o, e
 
 
-@pytest.mark.parametrize("name,steps", [("C1", 120), ("C2", 120), ("C3", 100), ("C4", 60), ("C5", 40)])
+@pytest.mark.parametrize("name,steps", [("C1", 120), ("C2", 120), ("C3", 100), ("C4", 60), ("C5", 40), ("STRESS", 150),
+                                        ("MAXCAP", 40), ("FLOORS", 120)])
 def test_lockstep_state_parity(name, steps):
     _lockstep(name, 2, steps)
 

@@ -30,7 +30,8 @@ def _dev_cmds(cmds):
     return t
 
 
-@pytest.mark.parametrize("name,steps", [("C1", 200), ("C2", 200), ("C3", 150), ("C4", 80), ("C5", 40)])
+@pytest.mark.parametrize("name,steps", [("C1", 200), ("C2", 200), ("C3", 150), ("C4", 80), ("C5", 40), ("STRESS", 300),
+                                        ("MAXCAP", 60), ("FLOORS", 200)])
 def test_lockstep_state_parity(name, steps):
     w, o, g = _pair(name, 3)
     cmds, _ = config.bench_commands(3, w.cfg.n_agents, steps)
@@ -44,7 +45,9 @@ def test_lockstep_state_parity(name, steps):
     assert (o.done() == g.done()).all()
 
 
-@pytest.mark.parametrize("name,arenas,steps,k", [("C2", 256, 300, 50), ("C3", 128, 240, 60), ("C5", 16, 60, 20)])
+@pytest.mark.parametrize("name,arenas,steps,k", [("C2", 256, 300, 50), ("C3", 128, 240, 60), ("C5", 16, 60, 20),
+                                                 ("STRESS", 64, 1200, 100), ("MAXCAP", 8, 120, 40),
+                                                 ("FLOORS", 32, 600, 75), ("C4", 32, 300, 50)])
 def test_multi_step_launch_digest(name, arenas, steps, k):
     w, o, g = _pair(name, arenas)
     cmds, _ = config.bench_commands(arenas, w.cfg.n_agents, steps)
@@ -114,7 +117,7 @@ def _ulp_diff(x, y):
     return np.abs(xi - yi)
 
 
-@pytest.mark.parametrize("name,steps", [("C2", 60), ("C3", 120), ("C5", 40)])
+@pytest.mark.parametrize("name,steps", [("C2", 60), ("C3", 120), ("C5", 40), ("MAXCAP", 50), ("FLOORS", 150), ("STRESS", 200)])
 def test_observation_parity(name, steps):
     w, o, g = _pair(name, 8)
     cmds, _ = config.bench_commands(8, w.cfg.n_agents, steps)
