@@ -8,13 +8,21 @@ Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>
 their own runs) into profiles/pmc_summary.json, keyed by workload/arenas/steps-per-launch.
 """
 import csv
-import glob
+import glob as _glob
 import json
 import os
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class glob:  # gpurun merges every call's outputs into gpurun_out/: only the newest file of a pattern is current
+    @staticmethod
+    def glob(pattern):
+        files = sorted(_glob.glob(pattern), key=os.path.getmtime)
+        return files[-1:]
+
 tag, workload, arenas, kpl = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
@@ -31,6 +39,16 @@ for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
         for r in keep:
             r["Duration_Ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             w.writerow(r)
+    # the bench's timed region = the last `steps / kpl` k_step dispatches before the K = 1 interactive section:
+    # take the k_step dispatches longer than half the longest one (K = kpl launches; K = 1 launches are ~20x shorter)
+    d = [r["Duration_Ns"] for r in keep if "k_step" in r["Kernel_Name"]]
+    big = [x for x in d if x > 0.5 * max(d)] if d else []
+    summary = {"k_step_dispatches": len(d), "k_step_K%d_dispatches" % kpl: len(big),
+               "k_step_K%d_avg_ms" % kpl: sum(big) / len(big) / 1e6 if big else None,
+               "k_observe_avg_ms": (lambda o: sum(o) / len(o) / 1e6 if o else None)(
+                   [r["Duration_Ns"] for r in keep if "k_observe" in r["Kernel_Name"]])}
+    json.dump(summary, open(os.path.join(dst, tag + "_kernel_summary.json"), "w"), indent=1)
+    print(summary)
 
 pmc = {}
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
