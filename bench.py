@@ -139,7 +139,7 @@ def main():
 
     # the interactive loop an RL learner runs: one launch per step (K = 1) + the observation of every agent
     obs_n = 0 if args.no_interactive else 40
-    loop_ms = obs_ms = k1_ms = 0.0
+    loop_ms = obs_ms = k1_ms = host_ms = 0.0
     if obs_n:
         d_obs = torch.empty(args.arenas * cfg.n_agents * 30752, dtype=torch.float32, device="cuda")
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -160,6 +160,12 @@ def main():
         loop_ms = ev[0].elapsed_time(ev[1]) / obs_n
         obs_ms = ev[1].elapsed_time(ev[2]) / obs_n
         k1_ms = ev[2].elapsed_time(ev[3]) / obs_n
+        # PCIe-inclusive: sf_step() with a host command array (H2D copy of arenas*agents bytes + K=1 launch)
+        t1 = time.perf_counter()
+        for s in range(obs_n):
+            g.step(cmds[s % total])
+        g.synchronize()
+        host_ms = (time.perf_counter() - t1) * 1e3 / obs_n
     g.kernel_time(False)
 
     if world > 1:
@@ -203,6 +209,7 @@ def main():
               "what": "per rank: K=1 launch per step + sf_observe_device for every agent, %d steps" % obs_n,
               "env_steps_per_s": world * args.arenas / (loop_ms / 1e3),
               "ms_per_step": loop_ms, "k_step_K1_ms": k1_ms, "k_observe_ms": obs_ms,
+            "sf_step_host_cmd_ms": host_ms,
               "k_observe_roofline": {"bound": "hbm", "achieved": obs_bytes / (obs_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": obs_bytes / (obs_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                                      "algorithmic_bytes_per_agent_step": 30752 * 4 + 961 * 8},

@@ -176,6 +176,10 @@ def baseline_workload(which, arenas=None, device=0, auto_reset=1):
         cfg = make_config(arenas or 2, 20, 30, floors=3, H=12, Z=10, B=32, P=8, mode=abi.MODE_SQUAD, n_agents=3,
                           device=device, auto_reset=auto_reset)
         m, p = three_floor_map(20, 30)
+    elif which == "NATIVE":  # the reference's own dimensions F=3, N=30, M=100 (gameplay.hpp:37) on a synthetic 3-floor map
+        cfg = make_config(arenas or 2, 30, 100, floors=3, H=64, Z=64, B=256, P=32, mode=abi.MODE_SOLO, level=2,
+                          device=device, auto_reset=auto_reset)
+        m, p = three_floor_map(30, 100, wall_p=0.06, map_seed=11)
     elif which == "STRESS":  # not a BASELINE config: tiny slot pools so that every allocator runs dry
         cfg = make_config(arenas or 8, 24, 40, H=6, Z=12, B=5, P=3, chests=6, mode=abi.MODE_TIMER, device=device,
                           auto_reset=auto_reset, timer_frames=600)

@@ -17,7 +17,7 @@ from oracle_lib import Oracle  # noqa: E402
 from strikeforce_amd import config  # noqa: E402
 
 CASES = [("C1", 2, 300), ("C2", 2, 300), ("C3", 2, 200), ("C4", 2, 100), ("C5", 2, 60), ("STRESS", 2, 300),
-         ("FLOORS", 2, 200), ("MAXCAP", 1, 60)]
+         ("FLOORS", 2, 200), ("MAXCAP", 1, 60), ("NATIVE", 2, 400)]
 CHECKPOINTS = 4
 
 

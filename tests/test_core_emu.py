@@ -29,7 +29,7 @@ def _lockstep(name, arenas, steps, check_every=1, **kw):
 
 
 @pytest.mark.parametrize("name,steps", [("C1", 120), ("C2", 120), ("C3", 100), ("C4", 60), ("C5", 40), ("STRESS", 150),
-                                        ("MAXCAP", 40), ("FLOORS", 120)])
+                                        ("MAXCAP", 40), ("FLOORS", 120), ("NATIVE", 150)])
 def test_lockstep_state_parity(name, steps):
     _lockstep(name, 2, steps)
 

@@ -31,7 +31,7 @@ def _dev_cmds(cmds):
 
 
 @pytest.mark.parametrize("name,steps", [("C1", 200), ("C2", 200), ("C3", 150), ("C4", 80), ("C5", 40), ("STRESS", 300),
-                                        ("MAXCAP", 60), ("FLOORS", 200)])
+                                        ("MAXCAP", 60), ("FLOORS", 200), ("NATIVE", 250)])
 def test_lockstep_state_parity(name, steps):
     w, o, g = _pair(name, 3)
     cmds, _ = config.bench_commands(3, w.cfg.n_agents, steps)
@@ -47,7 +47,7 @@ def test_lockstep_state_parity(name, steps):
 
 @pytest.mark.parametrize("name,arenas,steps,k", [("C2", 256, 300, 50), ("C3", 128, 240, 60), ("C5", 16, 60, 20),
                                                  ("STRESS", 64, 1200, 100), ("MAXCAP", 8, 120, 40),
-                                                 ("FLOORS", 32, 600, 75), ("C4", 32, 300, 50)])
+                                                 ("FLOORS", 32, 600, 75), ("C4", 32, 300, 50), ("NATIVE", 64, 1500, 100)])
 def test_multi_step_launch_digest(name, arenas, steps, k):
     w, o, g = _pair(name, arenas)
     cmds, _ = config.bench_commands(arenas, w.cfg.n_agents, steps)

@@ -1,0 +1,42 @@
+"""`.sf_sample` record/replay compatibility (reference format: gameplay.hpp:1771-1794,966-969; Character.hpp:570-648)."""
+import numpy as np
+
+from emu_lib import Emu
+from oracle_lib import Oracle
+from strikeforce_amd import abi, config, replay
+
+
+def _sample(n=400, seed=7):
+    rng = np.random.RandomState(seed)
+    cmds = "".join(abi.BENCH_COMMANDS[i] for i in rng.randint(0, 28, size=n))
+    return replay.Sample(1771155561, 1073741823, config.HUMAN_ENEMY_TOKENS, cmds, name="1")
+
+
+def test_file_layout_matches_the_reference_logger(tmp_path):
+    s = _sample(5)
+    p = tmp_path / "x.sf_sample"
+    replay.write_sample(str(p), s)
+    lines = p.read_text().split("\n")
+    assert lines[0] == "1771155561 1073741823"      # log_file << tb << " " << serial_number << '\n'
+    assert lines[1] == "1 0 1"                      # log_file << 1 << " " << ind << " " << 1 << '\n'
+    assert lines[2] == "1" and lines[3] == "1000"   # Human::log_file: name, def_Hp, ...
+    assert len(lines) == 2 + 33 + 5 + 1             # header, blob (name + 32 ints), 5 commands, trailing newline
+    assert [ln for ln in lines[35:40]] == list(s.commands)
+
+
+def test_round_trip_and_replay_is_deterministic(tmp_path):
+    s = _sample()
+    p = tmp_path / "game.sf_sample"
+    replay.write_sample(str(p), s)
+    r = replay.read_sample(str(p))
+    assert (r.tb, r.serial, r.ind, r.team, r.profile_tokens, r.commands) == (
+        s.tb, s.serial, s.ind, s.team, s.profile_tokens, s.commands)
+    m, portal = config.synthetic_map(30, 100, portal_pairs=2)
+    runs = []
+    for impl in (Oracle, Emu, Oracle):
+        w = replay.workload_for(r, 30, 100, m, portal, H=16, Z=32, B=64)
+        sim = impl(w)
+        n = replay.replay(r, sim)
+        runs.append((n, int(sim.digest()[0]), sim.results()[0, 0].tolist()))
+    assert runs[0] == runs[1] == runs[2]
+    assert runs[0][0] > 50
