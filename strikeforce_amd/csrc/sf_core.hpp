@@ -228,19 +228,6 @@ struct Core {
       }
     }
   }
-  static SF_DEV void bullet_kill(Arena &S, int idx) {
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-      if (j == (idx >> 6)) W::setlane(S.ba[j], (uint32_t)idx & 63u, 0u);
-  }
-  static SF_DEV uint32_t bullet_word(const V (&w)[NB], int idx) {
-    uint32_t r = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-      if (j == (idx >> 6)) r = W::readlane(w[j], (uint32_t)idx & 63u);
-    return r;
-  }
-
   // ------------------------------------------------------------------------------------------------
   // human field helpers (wave-uniform access to slot i)
   static SF_DEV int h_way(uint32_t fl) { return (int)(fl & HF_WAY_MASK); }

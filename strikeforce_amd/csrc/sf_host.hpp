@@ -153,7 +153,6 @@ struct Env {
   int16_t *d_map_pidx = nullptr;
   uint32_t *d_map_exits = nullptr;
   uint16_t *d_logt = nullptr;
-  Params *d_params = nullptr;
   uint32_t *d_exptab = nullptr;
   uint64_t *d_tb = nullptr, *d_serial = nullptr;
   uint8_t *d_cmd = nullptr;
@@ -257,7 +256,7 @@ struct Env {
     }
     // device state
     const size_t A = (size_t)p.A;
-    if ((rc = alloc(d_params, 1)) || (rc = alloc(d_logt, 65536)) || (rc = alloc(d_exptab, 512)) || (rc = alloc(d_tab, 1)) || (rc = alloc(d_map_flags, (size_t)p.cells_pad)) || (rc = alloc(d_map_pidx, (size_t)cells)) ||
+    if ((rc = alloc(d_logt, 65536)) || (rc = alloc(d_exptab, 512)) || (rc = alloc(d_tab, 1)) || (rc = alloc(d_map_flags, (size_t)p.cells_pad)) || (rc = alloc(d_map_pidx, (size_t)cells)) ||
         (rc = alloc(d_map_exits, (size_t)p.P)) || (rc = alloc(p.hum, HW_WORDS * A * p.H)) ||
         (rc = alloc(p.zom, ZW_WORDS * A * p.Z)) || (rc = alloc(p.bul, BW_WORDS * A * p.B)) ||
         (rc = alloc(p.por, A * p.P)) || (rc = alloc(p.rng, A * RNG_WORDS)) || (rc = alloc(p.rng2, A * RNG_WORDS)) || (rc = alloc(p.scal, A * SC_WORDS)) ||
@@ -276,13 +275,11 @@ struct Env {
     rt.zero(p.scal, A * SC_WORDS * sizeof(int32_t));
     p.logt = d_logt, p.exptab = d_exptab;
     p.tab = d_tab, p.map_flags = d_map_flags, p.map_pidx = d_map_pidx, p.map_exits = d_map_exits;
-    p.self = d_params;
-    rt.h2d(d_params, &p, sizeof p);
     return rt.sync();
   }
 
   void destroy() {
-    void *ptrs[] = {d_params, d_logt, d_exptab, d_tab, d_map_flags, d_map_pidx, d_map_exits, p.hum, p.zom, p.bul, p.por, p.rng, p.rng2, p.scal, p.results,
+    void *ptrs[] = {d_logt, d_exptab, d_tab, d_map_flags, d_map_pidx, d_map_exits, p.hum, p.zom, p.bul, p.por, p.rng, p.rng2, p.scal, p.results,
                     p.flags, p.aux_dmg, p.aux_pidx, d_tb, d_serial, d_cmd, d_obs};
     for (void *q : ptrs)
       if (q) rt.free(q);

@@ -100,7 +100,6 @@ struct Params {
   const uint8_t *map_flags;  // [cells_pad]
   const int16_t *map_pidx;   // [cells]
   const uint32_t *map_exits; // [P]
-  const Params *self;        // this struct in HBM, for out-of-line (rare-path) device functions
   const uint16_t *logt;      // [65536] log_3(v) for v = 1..65536 at index v-1 (RNG, sf_core.hpp draw())
   const uint32_t *exptab;    // [512] 3^i (i < 256) then 3^(256 i): staged in LDS behind the flag plane
 };

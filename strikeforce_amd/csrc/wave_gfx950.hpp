@@ -9,7 +9,6 @@
 #include <stdint.h>
 
 #define SF_DEV __device__ __forceinline__
-#define SF_NOINLINE __device__ __attribute__((noinline))
 
 namespace sf {
 
@@ -88,8 +87,6 @@ struct WaveGfx950 {
   static SF_DEV void ustore_i32(int32_t *p, int32_t v) {
     if (threadIdx.x == 0) __hip_atomic_store(gptr(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
-  // read-only table (never written by a kernel): plain load, the compiler may use the scalar cache
-  static SF_DEV uint32_t uload_u16c(const uint16_t *p) { return uni((uint32_t)*gptr(p)); }
   static SF_DEV V gload_u16(const uint16_t *base, V idx, P pred) { return pred ? (uint32_t)gptr(base)[idx] : 0u; }
   static SF_DEV int32_t uload_i16(const int16_t *p) {
     return (int32_t)(int16_t)uni((uint32_t)(uint16_t)__hip_atomic_load(gptr(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));

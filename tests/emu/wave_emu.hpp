@@ -9,7 +9,6 @@
 #include <string.h>
 
 #define SF_DEV inline
-#define SF_NOINLINE inline
 
 namespace sf {
 
@@ -141,7 +140,6 @@ struct WaveEmu {
     return r;
   }
   static uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return lds[idx]; }
-  static uint32_t uload_u16c(const uint16_t *p) { return *p; }
   static V gload_u16(const uint16_t *base, const V &idx, P pred) {
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? base[idx.v[i]] : 0u;
