@@ -92,10 +92,17 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the simulator has no CPU path")
+    # SF_BENCH_BACKEND=gloo + SF_BENCH_DEVICE=0 let the N > 1 control flow be rehearsed on a one-GPU box (two ranks on
+    # one card; RCCL refuses that).  The driver's multi-GPU runs use neither: backend nccl (= RCCL), device = LOCAL_RANK.
+    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("SF_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     w = config.baseline_workload(args.workload, arenas=args.arenas, device=local)
     cfg = w.cfg
@@ -119,7 +126,11 @@ def main():
             g.step_device(d_cmds.data_ptr() + s * stride, k)
             if world > 1:  # end-of-episode result records, RCCL over xGMI
                 g.results_device(res_local.data_ptr())
-                dist.all_gather_into_tensor(res_all, res_local)
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(res_all, res_local)
+                else:  # rehearsal backend: through host memory
+                    torch.cuda.current_stream().synchronize()
+                    shard.gather_results(res_local.cpu(), world)
             s += k
 
     run(0, args.warmup)
@@ -169,7 +180,7 @@ def main():
     g.kernel_time(False)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
