@@ -27,6 +27,14 @@ def load_library():
             raise StrikeForceError(
                 "libstrikeforce_amd.so is missing: run `python -m strikeforce_amd.build` (hipcc, gfx950). "
                 "strikeforce_amd has no CPU path.")
+        # PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64.  If this library's copies (from /opt/rocm)
+        # were mapped first, a later `import torch` would bring a second HSA runtime into the process and
+        # torch.cuda would find no GPU.  Importing torch first makes the loader resolve our DT_NEEDED entries to
+        # the runtime that is already mapped (same sonames), so there is exactly one runtime either way.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.sf_create.argtypes = [C.POINTER(abi.Config), C.POINTER(vp)]
