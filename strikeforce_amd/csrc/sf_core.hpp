@@ -24,7 +24,9 @@ namespace sf {
 enum { SH_WALL, SH_HUMAN, SH_ZOMBIE, SH_PUP, SH_PDN, SH_BULLET, SH_CHEST, SH_POUT, SH_EMPTY };
 enum { LIM_PORTAL = 1000, LIM_BLOCK = 1100 };  // G:37
 
-template <class W, int NB>
+// SHARED: the workgroup holds several arenas (one per wavefront) that share an LDS copy of the RNG's log table
+// (see draw_core); otherwise one wavefront = one workgroup and the log lookup goes to HBM/L2.
+template <class W, int NB, bool SHARED = false>
 struct Core {
   using V = typename W::V;
   using P = typename W::P;
@@ -44,6 +46,9 @@ struct Core {
     // _srand's 1024 serial draws (RN:73-74): log state, seed digits, draws done so far (0..1024)
     V rl2, rseed2;
     uint32_t warm;
+    // RNG tables: 3^i / 3^(256 i) (LDS) and, when SHARED, log3(v) for v = 1..32768 (LDS)
+    const uint32_t *xt;
+    const uint16_t *lt;
     // wave-uniform scalars  G:461
     int32_t frame, kills, tkills, loot, chests, steps, episodes, done, outcome, ended;
     uint32_t jomle, draws;
@@ -70,40 +75,43 @@ struct Core {
   // 16-step square-and-multiply chain, and the new value's log is one HBM/L2 lookup in the 64 Ki-entry log table.
   // Bit-identical to RN:54-62 by construction (checked against the reference's known answers).
   static constexpr uint32_t RL_ZERO = 0x10000u;  // random[i] == 0 (only until the first 18 draws after _srand)
-  static SF_DEV const uint32_t *exp_lo(const uint8_t *lds, const Params &p) {
-    return reinterpret_cast<const uint32_t *>(lds + p.cells_pad);
-  }
-  static SF_DEV V pow3_v(const uint8_t *lds, const Params &p, V m, P pred) {  // 3^m mod 65537, m < 65536
-    const uint32_t *t = exp_lo(lds, p);
-    return mulmod_v(W::lds_u32(t, m & 255u, pred), W::lds_u32(t + 256, m >> 8, pred));
-  }
-  static SF_DEV uint32_t pow3_u(const uint8_t *lds, const Params &p, uint32_t m) {
-    const uint32_t *t = exp_lo(lds, p);
-    return mulmod_u(W::ulds_u32(t, m & 255u), W::ulds_u32(t + 256, m >> 8));
+  static SF_DEV V pow3_v(const uint32_t *xt, V m, P pred) {  // 3^m mod 65537, m < 65536
+    return mulmod_v(W::lds_u32(xt, m & 255u, pred), W::lds_u32(xt + 256, m >> 8, pred));
   }
 
   // The scalar unit is shared by the four SIMDs of a CU and is this kernel's scarcest resource (measured:
   // SQ_INSTS_SALU ~ SQ_INSTS_VALU, one scalar issue per cycle per CU), so the wave-uniform tail of a draw
   // (mod, log lookup, power) is deliberately computed on the vector unit, redundantly in every lane, and only the
   // 10-bit result goes back to an SGPR.
+  // The log lookup is the longest link of the draw's dependency chain (a wave spends half its life waiting for
+  // it when it goes to L2).  In the SHARED layout the table sits in LDS: 3^32768 = -1, so log3(65537 - x) =
+  // log3(x) + 32768 and only x <= 32768 is stored (64 KiB), which 16 wavefronts of a workgroup share.
   template <bool WANT_OUT>
-  static SF_DEV V draw_core(V &rl, const V &rus, const V &rseed, uint32_t &jomle, const uint8_t *lds, const Params &p) {
+  static SF_DEV V draw_core(V &rl, const V &rus, const V &rseed, uint32_t &jomle, const uint32_t *xt, const uint16_t *lt,
+                            const Params &p) {
     const P tap = W::ltu(W::lane(), 18u) & ((rl & RL_ZERO) == 0u);
-    const V pw = pow3_v(lds, p, (rl * rseed) & 0xffffu, tap);  // p[random[i]][seed[i]] = random[i]^seed[i]
+    const V pw = pow3_v(xt, (rl * rseed) & 0xffffu, tap);  // p[random[i]][seed[i]] = random[i]^seed[i]
     const V sum = W::vec(W::sum18(W::select(tap, rus * pw, V(0u))) + 1u);  // < 2^24, same in every lane
     V t = (sum & 0xffffu) - (sum >> 16);
     t = t + (W::sar31(t) & 65537u);
     t = W::select(t == 0u, V(1u), t);  // binpow(sum + (int)(sum == 0), ...)
     jomle += 1u;
     const uint32_t e = jomle & 0xffffu;  // b %= mod - 1
-    const V lnew = (W::gload_u16(p.logt, t - 1u, W::all()) * e) & 0xffffu;
+    V lg;
+    if (SHARED) {
+      const P upper = W::ltu(V(32768u), t);
+      lg = W::lds_u16(lt, W::select(upper, V(65537u) - t, t) - 1u, W::all()) + W::select(upper, V(32768u), V(0u));
+    } else {
+      lg = W::gload_u16(p.logt, t - 1u, W::all());
+    }
+    const V lnew = (lg * e) & 0xffffu;
     rl = W::select(W::lane() == 17u, lnew, W::shl1(rl));  // the 17 swaps: rotate left, new value last
-    if (WANT_OUT) return pow3_v(lds, p, lnew, W::all()) & 1023u;
+    if (WANT_OUT) return pow3_v(xt, lnew, W::all()) & 1023u;
     return V(0u);
   }
-  static SF_DEV uint32_t draw(Arena &S, const uint8_t *lds, const Params &p) {  // RN:54-62
+  static SF_DEV uint32_t draw(Arena &S, const uint8_t *, const Params &p) {  // RN:54-62
     S.draws += 1u;
-    return W::first(draw_core<true>(S.rl, S.rus, S.rseed, S.jomle, lds, p));
+    return W::first(draw_core<true>(S.rl, S.rus, S.rseed, S.jomle, S.xt, S.lt, p));
   }
 
   static SF_DEV void seed_digits(V &digits, uint64_t x) {  // RN:65-68: decimal digit i of x, plus one, on lane i
@@ -118,12 +126,14 @@ struct Core {
     seed_digits(S.rus, us);
     seed_digits(S.rseed, tb);
     S.jomle = 18u;
-    for (int i = 0; i < 1024; ++i) draw_core<false>(S.rl, S.rus, S.rseed, S.jomle, lds, p);
+    (void)lds;
+    for (int i = 0; i < 1024; ++i) draw_core<false>(S.rl, S.rus, S.rseed, S.jomle, S.xt, S.lt, p);
   }
   // advance the next episode's warm-up by up to n draws
   static SF_DEV void prewarm(Arena &S, const uint8_t *lds, const Params &p, uint32_t n) {
     uint32_t j2 = 18u + S.warm;
-    for (; n && S.warm < 1024u; --n, ++S.warm) draw_core<false>(S.rl2, S.rus, S.rseed2, j2, lds, p);
+    (void)lds;
+    for (; n && S.warm < 1024u; --n, ++S.warm) draw_core<false>(S.rl2, S.rus, S.rseed2, j2, S.xt, S.lt, p);
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -1068,7 +1078,7 @@ struct Core {
     W::gstore(p.por + (size_t)a * (size_t)p.P, ln, S.ppos, W::ltu(ln, (uint32_t)p.P));
     {
       const P in = W::ltu(ln, 18u), nz = in & ((S.rl & RL_ZERO) == 0u);
-      const V val = W::select(nz, pow3_v(lds, p, S.rl & 0xffffu, nz), V(0u));
+      const V val = W::select(nz, pow3_v(S.xt, S.rl & 0xffffu, nz), V(0u));
       W::gstore(p.rng + (size_t)a * RNG_WORDS, ln, val | (S.rus << 20) | (S.rseed << 24), in);
       W::gstore(p.rng2 + (size_t)a * RNG_WORDS, ln, (S.rl2 & 0x1ffffu) | (S.rseed2 << 24), in);
     }
@@ -1089,19 +1099,32 @@ struct Core {
 
   // ------------------------------------------------------------------------------------------------
   // kernel bodies
-  static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial) {
+  // `lds`: this arena's flag plane.  Stand-alone layout (SHARED = false): the power table follows the plane and is
+  // staged here.  SHARED: `xt` / `lt` were staged by the workgroup (sf_api.hip k_step_shared).
+  static SF_DEV void tables(Arena &S, uint8_t *lds, const Params &p, const uint32_t *xt, const uint16_t *lt) {
+    if (SHARED) {
+      S.xt = xt, S.lt = lt;
+    } else {
+      W::copy_g2l(lds + p.cells_pad, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
+      S.xt = reinterpret_cast<const uint32_t *>(lds + p.cells_pad), S.lt = nullptr;
+    }
+  }
+
+  static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial,
+                                const uint32_t *xt = nullptr, const uint16_t *lt = nullptr) {
     Arena S;
     S.episodes = 0, S.ended = 0;
-    W::copy_g2l(lds + p.cells_pad, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
+    tables(S, lds, p, xt, lt);
     S.rl2 = V(RL_ZERO), S.rseed2 = V(0u), S.warm = 0u;
     reset(S, lds, p, a, tb[a], serial[a], false);
     store(S, lds, p, a);
   }
 
   // cmds: [k][A][n_agents]
-  static SF_DEV void step_body(uint8_t *lds, const Params &p, int a, const uint8_t *cmds, int k) {
+  static SF_DEV void step_body(uint8_t *lds, const Params &p, int a, const uint8_t *cmds, int k,
+                               const uint32_t *xt = nullptr, const uint16_t *lt = nullptr) {
     Arena S;
-    W::copy_g2l(lds + p.cells_pad, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
+    tables(S, lds, p, xt, lt);
     load(S, lds, p, a);
     const P ag = W::ltu(W::lane(), (uint32_t)p.n_agents);
     for (int s = 0; s < k; ++s) {

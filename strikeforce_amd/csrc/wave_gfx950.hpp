@@ -31,7 +31,7 @@ struct WaveGfx950 {
   using V = uint32_t;
   using P = bool;
 
-  static SF_DEV V lane() { return threadIdx.x; }
+  static SF_DEV V lane() { return threadIdx.x & 63u; }  // workgroups are 1 or 16 wavefronts, x-dimension only
   static SF_DEV uint64_t ballot(P p) { return __builtin_amdgcn_ballot_w64(p); }
   static SF_DEV int ctz64(uint64_t m) { return __builtin_ctzll(m); }
   static SF_DEV int clz64(uint64_t m) { return __builtin_clzll(m); }
@@ -40,13 +40,13 @@ struct WaveGfx950 {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uni(idx));
   }
   static SF_DEV void setlane(V &v, uint32_t idx, uint32_t val) {
-    v = (threadIdx.x == uni(idx)) ? val : v;  // v_cmp + v_cndmask (this clang has no writelane builtin)
+    v = (lane() == uni(idx)) ? val : v;  // v_cmp + v_cndmask (this clang has no writelane builtin)
   }
   static SF_DEV V select(P p, V a, V b) { return p ? a : b; }
   static SF_DEV V sar31(V v) { return (uint32_t)((int32_t)v >> 31); }
   static SF_DEV P le0(V v) { return (int32_t)v <= 0; }
   static SF_DEV P ltu(V a, V b) { return a < b; }
-  static SF_DEV P frombits(uint64_t m) { return (m >> threadIdx.x) & 1ull; }
+  static SF_DEV P frombits(uint64_t m) { return (m >> lane()) & 1ull; }
   static SF_DEV P all() { return true; }
   // a wave-uniform value moved to a VGPR behind the optimiser's back, so that what is computed from it stays on
   // the vector unit (the scalar unit is shared by the CU's four SIMDs and is this kernel's bottleneck)
@@ -73,6 +73,7 @@ struct WaveGfx950 {
   static SF_DEV V lds_u8(const uint8_t *lds, V idx, P pred) { return pred ? (uint32_t)lds[idx] : 0u; }
   static SF_DEV uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return uni((uint32_t)lds[idx]); }
   static SF_DEV V lds_u32(const uint32_t *lds, V idx, P pred) { return pred ? lds[idx] : 0u; }
+  static SF_DEV V lds_u16(const uint16_t *lds, V idx, P pred) { return pred ? (uint32_t)lds[idx] : 0u; }
   static SF_DEV uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return uni(lds[idx]); }
   static SF_DEV void ulds_store_u8(uint8_t *lds, uint32_t idx, uint32_t val) {
     lds[idx] = (uint8_t)val;  // every lane writes the same byte: no divergence, one LDS pass
@@ -85,14 +86,14 @@ struct WaveGfx950 {
     return (int32_t)uni((uint32_t)__hip_atomic_load(gptr(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
   }
   static SF_DEV void ustore_i32(int32_t *p, int32_t v) {
-    if (threadIdx.x == 0) __hip_atomic_store(gptr(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (lane() == 0u) __hip_atomic_store(gptr(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
   static SF_DEV V gload_u16(const uint16_t *base, V idx, P pred) { return pred ? (uint32_t)gptr(base)[idx] : 0u; }
   static SF_DEV int32_t uload_i16(const int16_t *p) {
     return (int32_t)(int16_t)uni((uint32_t)(uint16_t)__hip_atomic_load(gptr(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
   }
   static SF_DEV void ustore_i16(int16_t *p, int16_t v) {
-    if (threadIdx.x == 0) __hip_atomic_store(gptr(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (lane() == 0u) __hip_atomic_store(gptr(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
 
   // per-lane HBM access (struct-of-arrays: consecutive lanes hit consecutive dwords)
@@ -104,13 +105,13 @@ struct WaveGfx950 {
 
   // flag plane <-> LDS, 16 B per lane per pass (nbytes is a multiple of 16)
   static SF_DEV void copy_g2l(uint8_t *lds, const uint8_t *g, uint32_t nbytes) {
-    for (uint32_t off = threadIdx.x * 16u; off < nbytes; off += 64u * 16u)
+    for (uint32_t off = lane() * 16u; off < nbytes; off += 64u * 16u)
       *reinterpret_cast<u32x4 *>(lds + off) = *reinterpret_cast<const SF_GLOBAL u32x4 *>(gptr(g) + off);
     __builtin_amdgcn_wave_barrier();
   }
   static SF_DEV void copy_l2g(uint8_t *g, const uint8_t *lds, uint32_t nbytes) {
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t off = threadIdx.x * 16u; off < nbytes; off += 64u * 16u)
+    for (uint32_t off = lane() * 16u; off < nbytes; off += 64u * 16u)
       *reinterpret_cast<SF_GLOBAL u32x4 *>(gptr(g) + off) = *reinterpret_cast<const u32x4 *>(lds + off);
   }
 };

@@ -11,7 +11,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstrikeforce_amd.so")
+# SF_LIBRARY_PATH: load another build of the same library (A/B timing of two builds inside one gpurun call)
+LIB_PATH = os.environ.get("SF_LIBRARY_PATH") or os.path.join(_HERE, "libstrikeforce_amd.so")
 _LIB = None
 
 

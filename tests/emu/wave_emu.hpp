@@ -140,6 +140,11 @@ struct WaveEmu {
     return r;
   }
   static uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return lds[idx]; }
+  static V lds_u16(const uint16_t *lds, const V &idx, P pred) {
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
+    return r;
+  }
   static V gload_u16(const uint16_t *base, const V &idx, P pred) {
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? base[idx.v[i]] : 0u;
