@@ -33,28 +33,6 @@ __global__ __launch_bounds__(64) void k_step(Params p, const uint8_t *cmds, int 
   Core<WaveGfx950, NB>::step_body(lds, p, (int)blockIdx.x, cmds, k);
 }
 
-// 16 arenas per workgroup, one wavefront each, sharing one LDS copy of the RNG's log table (64 KiB) and power table:
-// the log lookup is the longest link of every draw's dependency chain, and LDS answers in ~64 cycles where L2 takes
-// ~500.  After the cooperative table load and one barrier the wavefronts never synchronise again.
-template <int NB>
-__global__ __launch_bounds__(64 * SHARED_WAVES) void k_step_shared(Params p, const uint8_t *cmds, int k) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const uint32_t tid = threadIdx.x;
-  for (uint32_t off = tid * 16u; off < (uint32_t)SHARED_LOG_BYTES; off += 64u * SHARED_WAVES * 16u)
-    *reinterpret_cast<u32x4 *>(lds + off) =
-        *reinterpret_cast<const SF_GLOBAL u32x4 *>(gptr(reinterpret_cast<const uint8_t *>(p.logt)) + off);
-  for (uint32_t off = tid * 16u; off < (uint32_t)LDS_TABLE_BYTES; off += 64u * SHARED_WAVES * 16u)
-    *reinterpret_cast<u32x4 *>(lds + SHARED_LOG_BYTES + off) =
-        *reinterpret_cast<const SF_GLOBAL u32x4 *>(gptr(reinterpret_cast<const uint8_t *>(p.exptab)) + off);
-  __syncthreads();
-  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-  const int a = (int)blockIdx.x * SHARED_WAVES + (int)w;
-  if (a >= p.A) return;
-  Core<WaveGfx950, NB, true>::step_body(lds + SHARED_LOG_BYTES + LDS_TABLE_BYTES + (size_t)w * (size_t)p.cells_pad, p, a,
-                                        cmds, k, reinterpret_cast<const uint32_t *>(lds + SHARED_LOG_BYTES),
-                                        reinterpret_cast<const uint16_t *>(lds));
-}
-
 constexpr int OBS_W2 = SF_OBS_WINDOW * SF_OBS_WINDOW;  // 961
 constexpr int OBS_THREADS = 256;
 
@@ -330,8 +308,8 @@ struct HipRT {
   }
 
   template <int NB>
-  int do_step(const Params &p, const uint8_t *cmds, int k, bool shared) {
-    int rc = shared ? lds_attr(k_step_shared<NB>, lds_bytes_shared(p.cells_pad)) : lds_attr(k_step<NB>, lds_bytes_for(p.cells_pad));
+  int do_step(const Params &p, const uint8_t *cmds, int k) {
+    int rc = lds_attr(k_step<NB>, lds_bytes_for(p.cells_pad));
     if (rc) return rc;
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (timing) {
@@ -344,22 +322,18 @@ struct HipRT {
       ev = &events[used_events++];
       SF_HIP(hipEventRecord(ev->first, stream));
     }
-    if (shared)
-      hipLaunchKernelGGL(k_step_shared<NB>, dim3((unsigned)((p.A + SHARED_WAVES - 1) / SHARED_WAVES)), dim3(64 * SHARED_WAVES),
-                         lds_bytes_shared(p.cells_pad), stream, p, cmds, k);
-    else
-      hipLaunchKernelGGL(k_step<NB>, dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad), stream, p, cmds, k);
+    hipLaunchKernelGGL(k_step<NB>, dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad), stream, p, cmds, k);
     SF_HIP(hipGetLastError());
     if (ev) SF_HIP(hipEventRecord(ev->second, stream));
     return SF_OK;
   }
-  int launch_step(const Params &p, int NB, const uint8_t *cmds, int k, bool shared) {
+  int launch_step(const Params &p, int NB, const uint8_t *cmds, int k) {
     SF_HIP(hipSetDevice(device));
     switch (NB) {
-      case 1: return do_step<1>(p, cmds, k, shared);
-      case 2: return do_step<2>(p, cmds, k, shared);
-      case 3: return do_step<3>(p, cmds, k, shared);
-      default: return do_step<4>(p, cmds, k, shared);
+      case 1: return do_step<1>(p, cmds, k);
+      case 2: return do_step<2>(p, cmds, k);
+      case 3: return do_step<3>(p, cmds, k);
+      default: return do_step<4>(p, cmds, k);
     }
   }
   int launch_observe(const Params &p, int, float *out) {

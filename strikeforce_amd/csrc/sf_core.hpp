@@ -24,9 +24,7 @@ namespace sf {
 enum { SH_WALL, SH_HUMAN, SH_ZOMBIE, SH_PUP, SH_PDN, SH_BULLET, SH_CHEST, SH_POUT, SH_EMPTY };
 enum { LIM_PORTAL = 1000, LIM_BLOCK = 1100 };  // G:37
 
-// SHARED: the workgroup holds several arenas (one per wavefront) that share an LDS copy of the RNG's log table
-// (see draw_core); otherwise one wavefront = one workgroup and the log lookup goes to HBM/L2.
-template <class W, int NB, bool SHARED = false>
+template <class W, int NB>
 struct Core {
   using V = typename W::V;
   using P = typename W::P;
@@ -46,9 +44,8 @@ struct Core {
     // _srand's 1024 serial draws (RN:73-74): log state, seed digits, draws done so far (0..1024)
     V rl2, rseed2;
     uint32_t warm;
-    // RNG tables: 3^i / 3^(256 i) (LDS) and, when SHARED, log3(v) for v = 1..32768 (LDS)
+    // RNG power table in LDS: 3^i (i < 256), then 3^(256 i)
     const uint32_t *xt;
-    const uint16_t *lt;
     // wave-uniform scalars  G:461
     int32_t frame, kills, tkills, loot, chests, steps, episodes, done, outcome, ended;
     uint32_t jomle, draws;
@@ -75,35 +72,36 @@ struct Core {
   // 16-step square-and-multiply chain, and the new value's log is one HBM/L2 lookup in the 64 Ki-entry log table.
   // Bit-identical to RN:54-62 by construction (checked against the reference's known answers).
   static constexpr uint32_t RL_ZERO = 0x10000u;  // random[i] == 0 (only until the first 18 draws after _srand)
+  // x mod 65537 for x < 2^32: lo16 - hi16, plus 65537 if that went negative (as unsigned: the smaller of the two)
+  static SF_DEV V mod65537_v(V x) {
+    const V t = (x & 0xffffu) - (x >> 16);
+    return W::minu(t, t + 65537u);
+  }
   static SF_DEV V pow3_v(const uint32_t *xt, V m, P pred) {  // 3^m mod 65537, m < 65536
-    return mulmod_v(W::lds_u32(xt, m & 255u, pred), W::lds_u32(xt + 256, m >> 8, pred));
+    // 3^lo (lo < 256) is never 65536 = 3^32768, so the product cannot wrap 2^32 and needs no corner term
+    return mod65537_v(W::lds_u32(xt, m & 255u, pred) * W::lds_u32(xt + 256, m >> 8, pred));
   }
 
   // The scalar unit is shared by the four SIMDs of a CU and is this kernel's scarcest resource (measured:
   // SQ_INSTS_SALU ~ SQ_INSTS_VALU, one scalar issue per cycle per CU), so the wave-uniform tail of a draw
   // (mod, log lookup, power) is deliberately computed on the vector unit, redundantly in every lane, and only the
   // 10-bit result goes back to an SGPR.
-  // The log lookup is the longest link of the draw's dependency chain (a wave spends half its life waiting for
-  // it when it goes to L2).  In the SHARED layout the table sits in LDS: 3^32768 = -1, so log3(65537 - x) =
-  // log3(x) + 32768 and only x <= 32768 is stored (64 KiB), which 16 wavefronts of a workgroup share.
+  // (Tried and dropped: a 16-arena workgroup sharing a 64 KiB LDS copy of the log table — log3(65537 - x) =
+  // log3(x) + 32768 halves it — measured equal to this L2 lookup within 2 %: the chain is bound by its ~45
+  // dependent ALU ops, not by the lookup.)
   template <bool WANT_OUT>
-  static SF_DEV V draw_core(V &rl, const V &rus, const V &rseed, uint32_t &jomle, const uint32_t *xt, const uint16_t *lt,
-                            const Params &p) {
+  static SF_DEV V draw_core(V &rl, const V &rus, const V &rseed, uint32_t &jomle, const uint32_t *xt, const Params &p) {
     const P tap = W::ltu(W::lane(), 18u) & ((rl & RL_ZERO) == 0u);
     const V pw = pow3_v(xt, (rl * rseed) & 0xffffu, tap);  // p[random[i]][seed[i]] = random[i]^seed[i]
-    const V sum = W::vec(W::sum18(W::select(tap, rus * pw, V(0u))) + 1u);  // < 2^24, same in every lane
-    V t = (sum & 0xffffu) - (sum >> 16);
-    t = t + (W::sar31(t) & 65537u);
+    // the sum stays on the vector unit: valid on lanes 16..31 (DPP row reductions + row_bcast:15), which is all that
+    // is needed — the new value is inserted on lane 17 and read back from lane 17
+    const V sum = W::sum18_row1(W::select(tap, rus * pw, V(0u))) + 1u;  // < 2^24
+    V t = mod65537_v(sum);
     t = W::select(t == 0u, V(1u), t);  // binpow(sum + (int)(sum == 0), ...)
     jomle += 1u;
     const uint32_t e = jomle & 0xffffu;  // b %= mod - 1
-    V lg;
-    if (SHARED) {
-      const P upper = W::ltu(V(32768u), t);
-      lg = W::lds_u16(lt, W::select(upper, V(65537u) - t, t) - 1u, W::all()) + W::select(upper, V(32768u), V(0u));
-    } else {
-      lg = W::gload_u16(p.logt, t - 1u, W::all());
-    }
+    // (& 65535: lanes outside 16..31 hold junk and must still read inside the table)
+    const V lg = W::gload_u16(p.logt, (t - 1u) & 65535u, W::all());
     const V lnew = (lg * e) & 0xffffu;
     rl = W::select(W::lane() == 17u, lnew, W::shl1(rl));  // the 17 swaps: rotate left, new value last
     if (WANT_OUT) return pow3_v(xt, lnew, W::all()) & 1023u;
@@ -111,7 +109,7 @@ struct Core {
   }
   static SF_DEV uint32_t draw(Arena &S, const uint8_t *, const Params &p) {  // RN:54-62
     S.draws += 1u;
-    return W::first(draw_core<true>(S.rl, S.rus, S.rseed, S.jomle, S.xt, S.lt, p));
+    return W::readlane(draw_core<true>(S.rl, S.rus, S.rseed, S.jomle, S.xt, p), 17u);
   }
 
   static SF_DEV void seed_digits(V &digits, uint64_t x) {  // RN:65-68: decimal digit i of x, plus one, on lane i
@@ -127,13 +125,13 @@ struct Core {
     seed_digits(S.rseed, tb);
     S.jomle = 18u;
     (void)lds;
-    for (int i = 0; i < 1024; ++i) draw_core<false>(S.rl, S.rus, S.rseed, S.jomle, S.xt, S.lt, p);
+    for (int i = 0; i < 1024; ++i) draw_core<false>(S.rl, S.rus, S.rseed, S.jomle, S.xt, p);
   }
   // advance the next episode's warm-up by up to n draws
   static SF_DEV void prewarm(Arena &S, const uint8_t *lds, const Params &p, uint32_t n) {
     uint32_t j2 = 18u + S.warm;
     (void)lds;
-    for (; n && S.warm < 1024u; --n, ++S.warm) draw_core<false>(S.rl2, S.rus, S.rseed2, j2, S.xt, S.lt, p);
+    for (; n && S.warm < 1024u; --n, ++S.warm) draw_core<false>(S.rl2, S.rus, S.rseed2, j2, S.xt, p);
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -289,34 +287,53 @@ struct Core {
 
   // ------------------------------------------------------------------------------------------------
   // spawns G:532-572 (loop top G:1444-1449)
-  static SF_DEV void spawn_chest(Arena &S, uint8_t *lds, const Params &p) {
-    if (p.C <= S.chests) return;
-    int i = (int)(draw(S, lds, p) % (uint32_t)p.F), j = (int)(draw(S, lds, p) % (uint32_t)p.N), k = (int)(draw(S, lds, p) % (uint32_t)p.M);
-    uint32_t fl;
-    if (showit(S, lds, p, i, j, k, fl) != SH_EMPTY) return;
-    uint32_t t = draw(S, lds, p) % 4u;
-    W::ulds_store_u8(lds, cellidx(p, i, j, k), fl | SF_CELL_CHEST | (t << SF_CELL_CONS_SHIFT));
-    S.dirty = 1u;
-    ++S.chests;
+  // Code-size note: this kernel's hot code has to stay resident in a 64 KiB instruction cache shared by two CUs
+  // while 32 wavefronts walk different parts of it, and every inlined draw() is ~0.4 KiB.  Phases that the
+  // reference writes out several times (three spawns, two half-ticks, three coordinate draws) are therefore kept as
+  // ONE body inside a non-unrolled loop; the order of draws is unchanged.
+#define SF_NOUNROLL _Pragma("clang loop unroll(disable)")
+
+  // `rand() % F, rand() % N, rand() % M` in that order (G:534,546,561,1850) as a packed position
+  static SF_DEV uint32_t draw_cell(Arena &S, const uint8_t *lds, const Params &p) {
+    uint32_t q = 0u;
+    SF_NOUNROLL for (int i = 0; i < 3; ++i) {
+      const uint32_t m = (uint32_t)(i == 0 ? p.F : i == 1 ? p.N : p.M);
+      q = (q << 10) | (draw(S, lds, p) % m);
+    }
+    return q;  // ((f << 10) | r) << 10 | c == pos_pack(f, r, c)
   }
-  static SF_DEV void spawn_zombie_npc(Arena &S, uint8_t *lds, const Params &p) {
-    int i = (int)(draw(S, lds, p) % (uint32_t)p.F), j = (int)(draw(S, lds, p) % (uint32_t)p.N), k = (int)(draw(S, lds, p) % (uint32_t)p.M);
-    uint32_t fl;
-    if (showit(S, lds, p, i, j, k, fl) != SH_EMPTY) return;
-    int index = z_ind(S, p);
-    if (index == -1) return;
-    uint32_t super_ = (draw(S, lds, p) % 4u == 0u) ? 1u : 0u;  // Zombie::gen_npc CH:850-857
-    W::setlane(S.zpos, (uint32_t)index, pos_pack(i, j, k) | ZF_ALIVE | (super_ ? ZF_SUPER : 0u));
-    W::setlane(S.zhp, (uint32_t)index, (super_ + 1u) * 400u);
-    W::setlane(S.zmd, (uint32_t)index, (super_ + 1u) * 100u);
-  }
-  static SF_DEV void spawn_human_npc(Arena &S, uint8_t *lds, const Params &p) {
-    int i = (int)(draw(S, lds, p) % (uint32_t)p.F), j = (int)(draw(S, lds, p) % (uint32_t)p.N), k = (int)(draw(S, lds, p) % (uint32_t)p.M);
-    uint32_t fl;
-    if (showit(S, lds, p, i, j, k, fl) != SH_EMPTY) return;
-    int index = h_ind(S, p);
-    if (index == -1) return;
-    human_make(S, p, (uint32_t)index, 1, pos_pack(i, j, k), 1, 0, HF_RNPC);
+
+  // spawn_chest / spawn_zombie_npc / spawn_human_npc G:532-572, at the loop top when frame % {30,40,50} <= 1
+  // (G:1444-1449), in that order
+  static SF_DEV void spawns(Arena &S, uint8_t *lds, const Params &p) {
+    const uint32_t due = (S.frame % 30 <= 1 ? 1u : 0u) | (S.frame % 40 <= 1 ? 2u : 0u) | (S.frame % 50 <= 1 ? 4u : 0u);
+    if (!due) return;
+    SF_NOUNROLL for (int kind = 0; kind < 3; ++kind) {
+      if (!((due >> kind) & 1u)) continue;
+      if (kind == 0 && p.C <= S.chests) continue;  // `if(C <= chest) return;` before any draw
+      const uint32_t q = draw_cell(S, lds, p);
+      uint32_t fl;
+      if (showit_q(S, lds, p, q, fl) != SH_EMPTY) continue;
+      int index = 0;
+      if (kind == 1) index = z_ind(S, p);
+      if (kind == 2) index = h_ind(S, p);
+      if (index == -1) continue;
+      if (kind == 2) {
+        human_make(S, p, (uint32_t)index, 1, q, 1, 0, HF_RNPC);  // gen_human CH:873-888
+        continue;
+      }
+      const uint32_t d4 = draw(S, lds, p) % 4u;
+      if (kind == 0) {  // `cons = gen_item(rand() % 4)`
+        W::ulds_store_u8(lds, cellidx_q(p, q), fl | SF_CELL_CHEST | (d4 << SF_CELL_CONS_SHIFT));
+        S.dirty = 1u;
+        ++S.chests;
+      } else {  // `super = (rand() % 4 == 0)`, Zombie::gen_npc CH:850-857
+        const uint32_t super_ = d4 == 0u ? 1u : 0u;
+        W::setlane(S.zpos, (uint32_t)index, q | ZF_ALIVE | (super_ ? ZF_SUPER : 0u));
+        W::setlane(S.zhp, (uint32_t)index, (super_ + 1u) * 400u);
+        W::setlane(S.zmd, (uint32_t)index, (super_ + 1u) * 100u);
+      }
+    }
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -395,7 +412,7 @@ struct Core {
       if (draw(S, lds, p) % 5u < 2u) continue;
       const uint32_t fb = W::readlane(freebits, z);
       const uint32_t zp = W::readlane(S.zpos, z);
-      for (int i1 = 0; i1 < 2; ++i1) {
+      SF_NOUNROLL for (int i1 = 0; i1 < 2; ++i1) {
         const uint32_t i2 = draw(S, lds, p) % 4u;
         if (!((fb >> i2) & 1u)) continue;
         const uint32_t q = (zp & POS_MASK) + (i2 == 0u ? 1024u : i2 == 1u ? 1u : i2 == 2u ? 0u - 1024u : 0u - 1u);
@@ -811,17 +828,13 @@ struct Core {
 
   // human_rnpc_bot G:1927-1940
   static SF_DEV uint32_t human_rnpc_bot(Arena &S, const uint8_t *lds, const Params &p) {
-    if (S.frame % 50 <= 1) {
-      const uint32_t k = draw(S, lds, p) % 8u;
-      return (uint32_t)("cvbnm,./"[k]);
-    } else if (draw(S, lds, p) % 5u < 3u)
-      return 'x';
-    else if (draw(S, lds, p) % 5u < 3u) {
-      const uint32_t k = draw(S, lds, p) % 7u;
-      return (uint32_t)("12awsdp"[k]);
-    }
-    const uint32_t k = draw(S, lds, p) % 8u;
-    return (uint32_t)("+ufghj[]"[k]);
+    // every path starts with one draw; the non-'x' path always draws twice more (G:1928-1939)
+    const uint32_t d1 = draw(S, lds, p);
+    if (S.frame % 50 <= 1) return (uint32_t)("cvbnm,./"[d1 % 8u]);
+    if (d1 % 5u < 3u) return 'x';
+    const uint32_t d2 = draw(S, lds, p);
+    const uint32_t d3 = draw(S, lds, p);
+    return d2 % 5u < 3u ? (uint32_t)("12awsdp"[d3 % 7u]) : (uint32_t)("+ufghj[]"[d3 % 8u]);
   }
 
   // human_action G:965-1012.  S.hcmd holds this step's external commands on lanes < n_agents.
@@ -887,9 +900,7 @@ struct Core {
 
   // top of play()'s while(true): G:1444-1450
   static SF_DEV void loop_top(Arena &S, uint8_t *lds, const Params &p, int a) {
-    if (S.frame % 30 <= 1) spawn_chest(S, lds, p);
-    if (S.frame % 40 <= 1) spawn_zombie_npc(S, lds, p);
-    if (S.frame % 50 <= 1) spawn_human_npc(S, lds, p);
+    spawns(S, lds, p);
     const int out = check_end(S, p);
     if (out != SF_RUNNING) {
       S.done = 1, S.outcome = out;
@@ -898,9 +909,9 @@ struct Core {
   }
 
   // ------------------------------------------------------------------------------------------------
-  // setup() G:1231-1277 + load_data() G:1741-1925 for this arena, then the first loop top.
+  // setup() G:1231-1277 + load_data() G:1741-1925 for this arena (the caller then does `++frame` and the first loop top).
   // `adopt`: the generator state for this seed was already warmed up in S.rl2 (see prewarm)
-  static SF_DEV void reset(Arena &S, uint8_t *lds, const Params &p, int a, uint64_t tb, uint64_t serial, bool adopt) {
+  static SF_DEV void reset_state(Arena &S, uint8_t *lds, const Params &p, uint64_t tb, uint64_t serial, bool adopt) {
     S.frame = S.kills = S.tkills = S.loot = S.chests = S.steps = 0;
     S.done = 0, S.outcome = SF_RUNNING;
     S.draws = 0u;
@@ -925,67 +936,72 @@ struct Core {
       S.rl2 = V(RL_ZERO);
       S.warm = 0u;
     }
-    if (p.mode == SF_MODE_BATTLE) {  // G:1846-1859
-      for (int i = 0; i < p.n_agents; ++i)
-        human_make(S, p, (uint32_t)i, 0, POS_NONE, 1, p.tab->teams[i], HF_CTRL | (i ? HF_REMOTE : 0u));
-      // not yet on the map: clear the designation until placed
-      S.hfl = S.hfl & ~HF_OCC;
-      for (int i = 0; i < p.n_agents; ++i) {
+    // load_data(): who stands where.  Solo/Timer: the player at (0,1,1) (G:1905-1920).  Squad: the player at (0,3,1),
+    // four team-mates at (0,1,2..5), five opponents at (squad_floor,1,6..10), all built from the NPC record
+    // (G:1861-1903).  Battle: every commanded human, placed below on random '.' cells (G:1846-1859).
+    const int count = p.mode == SF_MODE_BATTLE ? p.n_agents : (p.mode == SF_MODE_SQUAD ? 10 : 1);
+    SF_NOUNROLL for (int i = 0; i < count; ++i) {
+      int prof = 0, team = 1;
+      uint32_t q = pos_pack(0, 1, 1), fl = HF_CTRL;
+      if (p.mode == SF_MODE_BATTLE) {
+        q = POS_NONE, team = p.tab->teams[i], fl = HF_CTRL | (i ? HF_REMOTE : 0u);
+      } else if (p.mode == SF_MODE_SQUAD) {
+        prof = i ? 1 : 0;
+        team = i < 5 ? 1 : 2;
+        q = i == 0 ? pos_pack(0, 3, 1) : pos_pack(i < 5 ? 0 : p.squad_floor, 1, i + 1);
+        fl = (i == 0 || i < p.n_agents) ? HF_CTRL : 0u;  // USE_AGENT_IN_SQUAD_NPCS G:1883-1885
+      }
+      human_make(S, p, (uint32_t)i, prof, q, 1, team, fl);
+    }
+    if (p.mode == SF_MODE_BATTLE) {
+      S.hfl = S.hfl & ~HF_OCC;  // not on the map until placed
+      SF_NOUNROLL for (int i = 0; i < p.n_agents; ++i) {
         const uint32_t way = draw(S, lds, p) % 4u + 1u;
-        for (int guard = 0; guard < (1 << 20); ++guard) {  // `while(true)` with an exit every wave reaches
-          int f = (int)(draw(S, lds, p) % (uint32_t)p.F), r = (int)(draw(S, lds, p) % (uint32_t)p.N), c = (int)(draw(S, lds, p) % (uint32_t)p.M);
+        SF_NOUNROLL for (int guard = 0; guard < (1 << 20); ++guard) {  // `while(true)` with an exit every wave reaches
+          const uint32_t q = draw_cell(S, lds, p);
           uint32_t fl;
-          if (showit(S, lds, p, f, r, c, fl) == SH_EMPTY) {
-            W::setlane(S.hpos, (uint32_t)i, pos_pack(f, r, c));
+          if (showit_q(S, lds, p, q, fl) == SH_EMPTY) {
+            W::setlane(S.hpos, (uint32_t)i, q);
             W::setlane(S.hfl, (uint32_t)i, ((W::readlane(S.hfl, (uint32_t)i) & ~HF_WAY_MASK) | way) | HF_OCC);
             break;
           }
         }
       }
-    } else if (p.mode == SF_MODE_SQUAD) {  // G:1861-1903
-      human_make(S, p, 0u, 0, pos_pack(0, 3, 1), 1, 1, HF_CTRL);
-      for (int i = 1; i < 5; ++i)
-        human_make(S, p, (uint32_t)i, 1, pos_pack(0, 1, i + 1), 1, 1, i < p.n_agents ? HF_CTRL : 0u);
-      for (int i = 5; i < 10; ++i)
-        human_make(S, p, (uint32_t)i, 1, pos_pack(p.squad_floor, 1, i + 1), 1, 2, i < p.n_agents ? HF_CTRL : 0u);
-    } else {  // Solo / Timer G:1905-1920
-      human_make(S, p, 0u, 0, pos_pack(0, 1, 1), 1, 1, HF_CTRL);
     }
-    ++S.frame;  // G:1441
-    loop_top(S, lds, p, a);
   }
 
   // One iteration of the loop body G:1452-1471 followed by the next loop top.
   static SF_DEV void step(Arena &S, uint8_t *lds, const Params &p, int a) {
     S.ended = 0;
     if (S.done) return;
-    zombie_action(S, lds, p);
-    portal_damage(S, lds, p);
-    update_tmp(S, lds, p, a);
-    hits(S);
-    ++S.frame;  // updmap G:489-495 clears render-only bits
-    update_bull(S, lds, p);
-    human_action(S, lds, p, a);
-    update_tmp(S, lds, p, a);
-    hits(S);
-    ++S.frame;
-    update_bull(S, lds, p);
+    // the two half-ticks share `update_tmp; hit_human; hit_zombie; ++frame; update_bull` (G:1457-1463,1465-1471)
+    SF_NOUNROLL for (int half = 0; half < 2; ++half) {
+      if (half == 0) {
+        zombie_action(S, lds, p);
+        portal_damage(S, lds, p);
+      } else {
+        human_action(S, lds, p, a);
+      }
+      update_tmp(S, lds, p, a);
+      hits(S);
+      ++S.frame;  // updmap G:489-495 clears render-only bits
+      update_bull(S, lds, p);
+    }
     ++S.steps;
     if (p.auto_reset) prewarm(S, lds, p, 4u);
-    loop_top(S, lds, p, a);
-    if (S.done) {
+    // the loop top; when the episode ends and auto_reset is on, once more for the episode that begins
+    SF_NOUNROLL for (int pass = 0; pass < 2; ++pass) {
+      loop_top(S, lds, p, a);
+      if (!S.done || pass == 1) break;
       S.ended = 1;
       ++S.episodes;
-      if (p.auto_reset) {
-        const uint64_t tb = (((uint64_t)S.tb_hi << 32) | S.tb_lo) + (uint64_t)(uint32_t)p.reseed;
-        const uint64_t sr = ((uint64_t)S.sr_hi << 32) | S.sr_lo;
-        // inlined on purpose: an out-of-line call gives the kernel a stack, and scratch-backed launches
-        // measured 10 % slower at K = 50 and 2x slower at K = 1 on MI355X
-        const int32_t ep = S.episodes;
-        reset(S, lds, p, a, tb, sr, true);
-        S.episodes = ep;
-        S.ended = 1;
-      }
+      if (!p.auto_reset) break;
+      const uint64_t tb = (((uint64_t)S.tb_hi << 32) | S.tb_lo) + (uint64_t)(uint32_t)p.reseed;
+      const uint64_t sr = ((uint64_t)S.sr_hi << 32) | S.sr_lo;
+      const int32_t ep = S.episodes;
+      reset_state(S, lds, p, tb, sr, true);
+      S.episodes = ep;
+      ++S.frame;  // G:1441
     }
   }
 
@@ -1099,32 +1115,27 @@ struct Core {
 
   // ------------------------------------------------------------------------------------------------
   // kernel bodies
-  // `lds`: this arena's flag plane.  Stand-alone layout (SHARED = false): the power table follows the plane and is
-  // staged here.  SHARED: `xt` / `lt` were staged by the workgroup (sf_api.hip k_step_shared).
-  static SF_DEV void tables(Arena &S, uint8_t *lds, const Params &p, const uint32_t *xt, const uint16_t *lt) {
-    if (SHARED) {
-      S.xt = xt, S.lt = lt;
-    } else {
-      W::copy_g2l(lds + p.cells_pad, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
-      S.xt = reinterpret_cast<const uint32_t *>(lds + p.cells_pad), S.lt = nullptr;
-    }
+  // LDS layout of a workgroup (= one wavefront = one arena): [flag plane : cells_pad][power table : 2 KiB]
+  static SF_DEV void tables(Arena &S, uint8_t *lds, const Params &p) {
+    W::copy_g2l(lds + p.cells_pad, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
+    S.xt = reinterpret_cast<const uint32_t *>(lds + p.cells_pad);
   }
 
-  static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial,
-                                const uint32_t *xt = nullptr, const uint16_t *lt = nullptr) {
+  static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial) {
     Arena S;
     S.episodes = 0, S.ended = 0;
-    tables(S, lds, p, xt, lt);
+    tables(S, lds, p);
     S.rl2 = V(RL_ZERO), S.rseed2 = V(0u), S.warm = 0u;
-    reset(S, lds, p, a, tb[a], serial[a], false);
+    reset_state(S, lds, p, tb[a], serial[a], false);
+    ++S.frame;  // G:1441
+    loop_top(S, lds, p, a);
     store(S, lds, p, a);
   }
 
   // cmds: [k][A][n_agents]
-  static SF_DEV void step_body(uint8_t *lds, const Params &p, int a, const uint8_t *cmds, int k,
-                               const uint32_t *xt = nullptr, const uint16_t *lt = nullptr) {
+  static SF_DEV void step_body(uint8_t *lds, const Params &p, int a, const uint8_t *cmds, int k) {
     Arena S;
-    tables(S, lds, p, xt, lt);
+    tables(S, lds, p);
     load(S, lds, p, a);
     const P ag = W::ltu(W::lane(), (uint32_t)p.n_agents);
     for (int s = 0; s < k; ++s) {

@@ -146,7 +146,6 @@ struct Env {
   Tables tab;
   int NB = 1, cells = 0;
   bool was_reset = false;
-  bool shared = false;  // step kernel variant: 16 arenas per workgroup sharing an LDS copy of the RNG log table
   RT rt;
   // device buffers
   Tables *d_tab = nullptr;
@@ -191,7 +190,6 @@ struct Env {
     p.timer_lim = cfg.level * (cfg.timer_frames_per_level > 0 ? cfg.timer_frames_per_level : 7500);
     p.squad_floor = cfg.floors > 2 ? 2 : cfg.floors - 1;
     NB = nb_for(p.B);
-    shared = lds_bytes_shared(p.cells_pad) <= rt.max_lds() && !getenv("SF_NO_SHARED_TABLES");
     if (lds_bytes_for(p.cells_pad) > rt.max_lds()) return fail(SF_ERR_ARG, "map does not fit the 160 KiB LDS flag plane");
     // tables
     derive_profile(cfg, cfg.player, tab.der[0]);
@@ -303,12 +301,12 @@ struct Env {
     if (!cmd) return fail(SF_ERR_ARG, "null command array");
     if (!was_reset) return fail(SF_ERR_STATE, "sf_step before sf_reset");
     rt.h2d(d_cmd, cmd, (size_t)p.A * p.n_agents);
-    return rt.launch_step(p, NB, d_cmd, 1, shared);
+    return rt.launch_step(p, NB, d_cmd, 1);
   }
   int step_device(const uint8_t *d_cmds, int k) {
     if (!d_cmds || k < 1) return fail(SF_ERR_ARG, "bad command buffer / step count");
     if (!was_reset) return fail(SF_ERR_STATE, "sf_step_device before sf_reset");
-    return rt.launch_step(p, NB, d_cmds, k, shared);
+    return rt.launch_step(p, NB, d_cmds, k);
   }
 
   int observe_device(float *d_out) {

@@ -107,11 +107,5 @@ struct Params {
 inline int nb_for(int B) { return (B + 63) / 64; }
 constexpr int LDS_TABLE_BYTES = 2048;  // exptab
 inline size_t lds_bytes_for(int cells_pad) { return (size_t)cells_pad + LDS_TABLE_BYTES; }
-// shared layout of k_step_shared: [log3 table for 1..32768 : 64 KiB][exptab : 2 KiB][SHARED_WAVES flag planes]
-constexpr int SHARED_WAVES = 16;
-constexpr int SHARED_LOG_BYTES = 65536;
-inline size_t lds_bytes_shared(int cells_pad) {
-  return (size_t)SHARED_LOG_BYTES + LDS_TABLE_BYTES + (size_t)SHARED_WAVES * (size_t)cells_pad;
-}
 
 }  // namespace sf

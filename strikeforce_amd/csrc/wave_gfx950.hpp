@@ -31,7 +31,7 @@ struct WaveGfx950 {
   using V = uint32_t;
   using P = bool;
 
-  static SF_DEV V lane() { return threadIdx.x & 63u; }  // workgroups are 1 or 16 wavefronts, x-dimension only
+  static SF_DEV V lane() { return threadIdx.x; }  // one 64-lane wavefront per workgroup
   static SF_DEV uint64_t ballot(P p) { return __builtin_amdgcn_ballot_w64(p); }
   static SF_DEV int ctz64(uint64_t m) { return __builtin_ctzll(m); }
   static SF_DEV int clz64(uint64_t m) { return __builtin_clzll(m); }
@@ -57,15 +57,18 @@ struct WaveGfx950 {
   }
   static SF_DEV uint32_t first(V v) { return uni(v); }
 
-  // sum over lanes 0..17 of a value that is zero on lanes >= 18: two DPP row reductions + two readlanes
-  static SF_DEV uint32_t sum18(V v) {
+  // sum over lanes 0..17 of a value that is zero on lanes >= 18, left on the vector unit: valid on lanes 16..31
+  // (DPP reductions inside each 16-lane row, then row 1 += row 0's total via row_bcast:15)
+  static SF_DEV V sum18_row1(V v) {
     int x = (int)v;
-    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
-    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
-    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);  // row_half_mirror
-    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);  // row_mirror
-    return (uint32_t)(__builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16));
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0x2, 0xf, false);  // row_bcast:15 into row 1 only
+    return (uint32_t)x;
   }
+  static SF_DEV V minu(V a, V b) { return a < b ? a : b; }
   // lane i <- lane i + 1 (wave_shl:1, a gfx9 DPP control); lane 63 reads 0
   static SF_DEV V shl1(V v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 
@@ -73,7 +76,6 @@ struct WaveGfx950 {
   static SF_DEV V lds_u8(const uint8_t *lds, V idx, P pred) { return pred ? (uint32_t)lds[idx] : 0u; }
   static SF_DEV uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return uni((uint32_t)lds[idx]); }
   static SF_DEV V lds_u32(const uint32_t *lds, V idx, P pred) { return pred ? lds[idx] : 0u; }
-  static SF_DEV V lds_u16(const uint16_t *lds, V idx, P pred) { return pred ? (uint32_t)lds[idx] : 0u; }
   static SF_DEV uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return uni(lds[idx]); }
   static SF_DEV void ulds_store_u8(uint8_t *lds, uint32_t idx, uint32_t val) {
     lds[idx] = (uint8_t)val;  // every lane writes the same byte: no divergence, one LDS pass

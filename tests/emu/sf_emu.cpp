@@ -26,18 +26,6 @@ static void run_step(const Params &p, const uint8_t *cmds, int k) {
   for (int a = 0; a < p.A; ++a) Core<WaveEmu, NB>::step_body(lds.data(), p, a, cmds, k);
 }
 
-// the SHARED layout of k_step_shared: [log3 table, first 32768 entries][power table][flag plane]
-template <int NB>
-static void run_step_shared(const Params &p, const uint8_t *cmds, int k) {
-  std::vector<uint8_t> lds(SHARED_LOG_BYTES + LDS_TABLE_BYTES + (size_t)p.cells_pad);
-  memcpy(lds.data(), p.logt, SHARED_LOG_BYTES);
-  memcpy(lds.data() + SHARED_LOG_BYTES, p.exptab, LDS_TABLE_BYTES);
-  for (int a = 0; a < p.A; ++a)
-    Core<WaveEmu, NB, true>::step_body(lds.data() + SHARED_LOG_BYTES + LDS_TABLE_BYTES, p, a, cmds, k,
-                                       reinterpret_cast<const uint32_t *>(lds.data() + SHARED_LOG_BYTES),
-                                       reinterpret_cast<const uint16_t *>(lds.data()));
-}
-
 static void run_observe(const Params &p, float *out) {
   const int W2 = SF_OBS_WINDOW * SF_OBS_WINDOW;
   std::vector<uint32_t> occ(W2);
@@ -108,16 +96,7 @@ struct CpuRT {
     }
     return SF_OK;
   }
-  int launch_step(const Params &p, int NB, const uint8_t *cmds, int k, bool shared) {
-    if (shared) {
-      switch (NB) {
-        case 1: run_step_shared<1>(p, cmds, k); break;
-        case 2: run_step_shared<2>(p, cmds, k); break;
-        case 3: run_step_shared<3>(p, cmds, k); break;
-        default: run_step_shared<4>(p, cmds, k); break;
-      }
-      return SF_OK;
-    }
+  int launch_step(const Params &p, int NB, const uint8_t *cmds, int k) {
     switch (NB) {
       case 1: run_step<1>(p, cmds, k); break;
       case 2: run_step<2>(p, cmds, k); break;
@@ -167,10 +146,4 @@ int sfe_dump_arena(sfe_env *env, int32_t a, sf_arena_hdr *hdr, sf_human_rec *hs,
   return env->e.dump_arena(a, hdr, hs, zs, bs, ps, cf, cd, cp);
 }
 const char *sfe_last_error(void) { return sf::last_error().c_str(); }
-/* test hook: force the step-kernel variant (0 stand-alone, 1 shared tables); returns the previous one */
-int sfe_set_shared(sfe_env *env, int shared) {
-  int old = env->e.shared;
-  env->e.shared = shared != 0;
-  return old;
-}
 }

@@ -117,10 +117,17 @@ struct WaveEmu {
   static P all() { return P{~0ull}; }
   static V vec(uint32_t x) { return V(x); }
   static uint32_t first(const V &v) { return v.v[0]; }
-  static uint32_t sum18(const V &a) {
-    uint32_t s = 0;
-    for (int i = 0; i < 32; ++i) s += a.v[i];  // rows 0 and 1, as the DPP reduction reads them
-    return s;
+  static V sum18_row1(const V &a) {  // like the DPP version: meaningful on lanes 16..31 only
+    uint32_t r0 = 0, r1 = 0;
+    for (int i = 0; i < 16; ++i) r0 += a.v[i], r1 += a.v[16 + i];
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = i < 16 ? r0 : (i < 32 ? r0 + r1 : 0xdeadbeefu);
+    return r;
+  }
+  static V minu(const V &a, const V &b) {
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i];
+    return r;
   }
   static V shl1(const V &a) {
     V r;

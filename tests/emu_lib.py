@@ -22,7 +22,6 @@ def lib(asan=False):
         abi.bind(L, "sfe_")
         L.sfe_step_many.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
         L.sfe_last_error.restype = C.c_char_p
-        L.sfe_set_shared.argtypes = [C.c_void_p, C.c_int]
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -37,10 +36,6 @@ class Emu:
         self.h = self.L.sfe_create(C.byref(self.cfg))
         if not self.h:
             raise ValueError("emu rejected the configuration: %s" % self.L.sfe_last_error().decode())
-
-    def set_shared(self, shared):
-        """Force the step variant: False = one arena per workgroup, True = shared LDS tables."""
-        return bool(self.L.sfe_set_shared(self.h, 1 if shared else 0))
 
     def close(self):
         if self.h:
