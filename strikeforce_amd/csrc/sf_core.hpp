@@ -46,6 +46,9 @@ struct Core {
     uint32_t warm;
     // RNG power table in LDS: 3^i (i < 256), then 3^(256 i)
     const uint32_t *xt;
+    // one-deep lookahead of draw(): the log looked up for the next draw, and whether it is valid
+    V la;
+    uint32_t la_ok;
     // wave-uniform scalars  G:461
     int32_t frame, kills, tkills, loot, chests, steps, episodes, done, outcome, ended;
     uint32_t jomle, draws;
@@ -107,9 +110,26 @@ struct Core {
     if (WANT_OUT) return pow3_v(xt, lnew, W::all()) & 1023u;
     return V(0u);
   }
+  // The draw the game logic consumes, software-pipelined one deep: the generator's sequence does not depend on the
+  // game, so the table lookup for draw n+1 (the one long-latency link of the chain) is issued at the end of draw
+  // n and waited for at the beginning of draw n+1; the logic in between runs under its latency.  `S.la` holds the
+  // looked-up log; it is a pure function of the committed state (rl, jomle), so it is simply dropped at store time.
+  static SF_DEV void draw_issue(Arena &S, const Params &p) {  // first half of draw_core, up to the lookup
+    const P tap = W::ltu(W::lane(), 18u) & ((S.rl & RL_ZERO) == 0u);
+    const V pw = pow3_v(S.xt, (S.rl * S.rseed) & 0xffffu, tap);
+    V t = mod65537_v(W::sum18_row1(W::select(tap, S.rus * pw, V(0u))) + 1u);
+    t = W::select(t == 0u, V(1u), t);
+    S.la = W::gload_u16(p.logt, (t - 1u) & 65535u, W::all());
+    S.la_ok = 1u;
+  }
   static SF_DEV uint32_t draw(Arena &S, const uint8_t *, const Params &p) {  // RN:54-62
+    if (!S.la_ok) draw_issue(S, p);
     S.draws += 1u;
-    return W::readlane(draw_core<true>(S.rl, S.rus, S.rseed, S.jomle, S.xt, p), 17u);
+    S.jomle += 1u;
+    const V lnew = (S.la * (S.jomle & 0xffffu)) & 0xffffu;
+    S.rl = W::select(W::lane() == 17u, lnew, W::shl1(S.rl));
+    draw_issue(S, p);  // draw n+1's lookup is now in flight
+    return W::readlane(pow3_v(S.xt, lnew, W::all()) & 1023u, 17u);
   }
 
   static SF_DEV void seed_digits(V &digits, uint64_t x) {  // RN:65-68: decimal digit i of x, plus one, on lane i
@@ -121,6 +141,7 @@ struct Core {
   }
   static SF_DEV void srand_(Arena &S, const uint8_t *lds, const Params &p, uint64_t tb, uint64_t us) {  // RN:64-76
     S.rl = V(RL_ZERO);
+    S.la_ok = 0u;
     seed_digits(S.rus, us);
     seed_digits(S.rseed, tb);
     S.jomle = 18u;
@@ -928,6 +949,7 @@ struct Core {
     if (adopt) {
       prewarm(S, lds, p, 1024u);  // whatever is still missing
       S.rl = S.rl2, S.rseed = S.rseed2, S.jomle = 18u + 1024u;
+      S.la_ok = 0u;
     } else {
       srand_(S, lds, p, tb, serial);
     }
@@ -1119,6 +1141,7 @@ struct Core {
   static SF_DEV void tables(Arena &S, uint8_t *lds, const Params &p) {
     W::copy_g2l(lds + p.cells_pad, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
     S.xt = reinterpret_cast<const uint32_t *>(lds + p.cells_pad);
+    S.la = V(0u), S.la_ok = 0u;
   }
 
   static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial) {
