@@ -21,16 +21,17 @@
 
 namespace sf {
 
-template <int NB>
+// HP (HBM_PLANE): maps whose flag plane is too large for LDS keep it in HBM (sf_core.hpp); dynamic LDS = power table only
+template <int NB, bool HP>
 __global__ __launch_bounds__(64) void k_reset(Params p, const uint64_t *tb, const uint64_t *serial) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  Core<WaveGfx950, NB>::reset_body(lds, p, (int)blockIdx.x, tb, serial);
+  Core<WaveGfx950, NB, HP>::reset_body(lds, p, (int)blockIdx.x, tb, serial);
 }
 
-template <int NB>
+template <int NB, bool HP>
 __global__ __launch_bounds__(64) void k_step(Params p, const uint8_t *cmds, int k) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  Core<WaveGfx950, NB>::step_body(lds, p, (int)blockIdx.x, cmds, k);
+  Core<WaveGfx950, NB, HP>::step_body(lds, p, (int)blockIdx.x, cmds, k);
 }
 
 constexpr int OBS_W2 = SF_OBS_WINDOW * SF_OBS_WINDOW;  // 961
@@ -291,9 +292,13 @@ struct HipRT {
 
   template <int NB>
   int do_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
-    int rc = lds_attr(k_reset<NB>, lds_bytes_for(p.cells_pad));
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_reset<NB>, dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad), stream, p, tb, serial);
+    if (hbm_plane(p.cells_pad)) {
+      hipLaunchKernelGGL((k_reset<NB, true>), dim3((unsigned)p.A), dim3(64), (size_t)LDS_TABLE_BYTES, stream, p, tb, serial);
+    } else {
+      int rc = lds_attr(k_reset<NB, false>, lds_bytes_for(p.cells_pad));
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_reset<NB, false>), dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad), stream, p, tb, serial);
+    }
     SF_HIP(hipGetLastError());
     return SF_OK;
   }
@@ -309,8 +314,11 @@ struct HipRT {
 
   template <int NB>
   int do_step(const Params &p, const uint8_t *cmds, int k) {
-    int rc = lds_attr(k_step<NB>, lds_bytes_for(p.cells_pad));
-    if (rc) return rc;
+    const bool hp = hbm_plane(p.cells_pad);
+    if (!hp) {
+      int rc = lds_attr(k_step<NB, false>, lds_bytes_for(p.cells_pad));
+      if (rc) return rc;
+    }
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (timing) {
       if (used_events == events.size()) {
@@ -322,7 +330,10 @@ struct HipRT {
       ev = &events[used_events++];
       SF_HIP(hipEventRecord(ev->first, stream));
     }
-    hipLaunchKernelGGL(k_step<NB>, dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad), stream, p, cmds, k);
+    if (hp)
+      hipLaunchKernelGGL((k_step<NB, true>), dim3((unsigned)p.A), dim3(64), (size_t)LDS_TABLE_BYTES, stream, p, cmds, k);
+    else
+      hipLaunchKernelGGL((k_step<NB, false>), dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad), stream, p, cmds, k);
     SF_HIP(hipGetLastError());
     if (ev) SF_HIP(hipEventRecord(ev->second, stream));
     return SF_OK;

@@ -24,7 +24,10 @@ namespace sf {
 enum { SH_WALL, SH_HUMAN, SH_ZOMBIE, SH_PUP, SH_PDN, SH_BULLET, SH_CHEST, SH_POUT, SH_EMPTY };
 enum { LIM_PORTAL = 1000, LIM_BLOCK = 1100 };  // G:37
 
-template <class W, int NB>
+// HBM_PLANE: the arena's flag plane is too large to stage in LDS next to enough other wavefronts (128x128 and up):
+// `lds` then points at the plane in HBM itself (L2-cached; the same accessors compile to global loads/stores) and
+// only the 2 KiB power table sits in LDS.
+template <class W, int NB, bool HBM_PLANE = false>
 struct Core {
   using V = typename W::V;
   using P = typename W::P;
@@ -1081,7 +1084,7 @@ struct Core {
     S.sr_lo = W::readlane(sc, SC_SR_LO), S.sr_hi = W::readlane(sc, SC_SR_HI);
     S.draws = W::readlane(sc, SC_DRAWS);
     S.warm = W::readlane(sc, SC_WARM);
-    W::copy_g2l(lds, p.flags + (size_t)a * (size_t)p.cells_pad, (uint32_t)p.cells_pad);
+    if (!HBM_PLANE) W::copy_g2l(lds, p.flags + (size_t)a * (size_t)p.cells_pad, (uint32_t)p.cells_pad);
     S.dirty = 0u;
   }
 
@@ -1132,22 +1135,25 @@ struct Core {
     W::setlane(sc, SC_DRAWS, S.draws);
     W::setlane(sc, SC_WARM, S.warm);
     W::gstore((uint32_t *)p.scal + (size_t)a * SC_WORDS, ln, sc, W::ltu(ln, (uint32_t)SC_WORDS));
-    if (S.dirty) W::copy_l2g(p.flags + (size_t)a * (size_t)p.cells_pad, lds, (uint32_t)p.cells_pad);
+    if (!HBM_PLANE && S.dirty) W::copy_l2g(p.flags + (size_t)a * (size_t)p.cells_pad, lds, (uint32_t)p.cells_pad);
   }
 
   // ------------------------------------------------------------------------------------------------
   // kernel bodies
-  // LDS layout of a workgroup (= one wavefront = one arena): [flag plane : cells_pad][power table : 2 KiB]
-  static SF_DEV void tables(Arena &S, uint8_t *lds, const Params &p) {
-    W::copy_g2l(lds + p.cells_pad, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
-    S.xt = reinterpret_cast<const uint32_t *>(lds + p.cells_pad);
+  // LDS layout of a workgroup (= one wavefront = one arena): [flag plane : cells_pad][power table : 2 KiB];
+  // with HBM_PLANE only the power table, and `lds` (the plane) is the arena's slice of Params::flags
+  static SF_DEV uint8_t *tables(Arena &S, uint8_t *lds, const Params &p, int a) {
+    uint8_t *tab = HBM_PLANE ? lds : lds + p.cells_pad;
+    W::copy_g2l(tab, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
+    S.xt = reinterpret_cast<const uint32_t *>(tab);
     S.la = V(0u), S.la_ok = 0u;
+    return HBM_PLANE ? p.flags + (size_t)a * (size_t)p.cells_pad : lds;
   }
 
   static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial) {
     Arena S;
     S.episodes = 0, S.ended = 0;
-    tables(S, lds, p);
+    lds = tables(S, lds, p, a);
     S.rl2 = V(RL_ZERO), S.rseed2 = V(0u), S.warm = 0u;
     reset_state(S, lds, p, tb[a], serial[a], false);
     ++S.frame;  // G:1441
@@ -1158,7 +1164,7 @@ struct Core {
   // cmds: [k][A][n_agents]
   static SF_DEV void step_body(uint8_t *lds, const Params &p, int a, const uint8_t *cmds, int k) {
     Arena S;
-    tables(S, lds, p);
+    lds = tables(S, lds, p, a);
     load(S, lds, p, a);
     const P ag = W::ltu(W::lane(), (uint32_t)p.n_agents);
     for (int s = 0; s < k; ++s) {

@@ -190,7 +190,8 @@ struct Env {
     p.timer_lim = cfg.level * (cfg.timer_frames_per_level > 0 ? cfg.timer_frames_per_level : 7500);
     p.squad_floor = cfg.floors > 2 ? 2 : cfg.floors - 1;
     NB = nb_for(p.B);
-    if (lds_bytes_for(p.cells_pad) > rt.max_lds()) return fail(SF_ERR_ARG, "map does not fit the 160 KiB LDS flag plane");
+    if (!hbm_plane(p.cells_pad) && lds_bytes_for(p.cells_pad) > rt.max_lds())
+      return fail(SF_ERR_ARG, "map does not fit the LDS flag plane");
     // tables
     derive_profile(cfg, cfg.player, tab.der[0]);
     derive_profile(cfg, cfg.npc, tab.der[1]);

@@ -107,5 +107,8 @@ struct Params {
 inline int nb_for(int B) { return (B + 63) / 64; }
 constexpr int LDS_TABLE_BYTES = 2048;  // exptab
 inline size_t lds_bytes_for(int cells_pad) { return (size_t)cells_pad + LDS_TABLE_BYTES; }
+// flag planes above this size stay in HBM (Core<.., HBM_PLANE>): staging them would leave < 12 wavefronts per CU
+constexpr int LDS_PLANE_MAX = 12 * 1024;
+inline bool hbm_plane(int cells_pad) { return cells_pad > LDS_PLANE_MAX; }
 
 }  // namespace sf

@@ -15,15 +15,26 @@
 
 namespace sf {
 
+// same variant choice as the HIP launchers: big flag planes stay in "HBM" (here: the host arrays)
 template <int NB>
 static void run_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
   std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad));
-  for (int a = 0; a < p.A; ++a) Core<WaveEmu, NB>::reset_body(lds.data(), p, a, tb, serial);
+  for (int a = 0; a < p.A; ++a) {
+    if (hbm_plane(p.cells_pad))
+      Core<WaveEmu, NB, true>::reset_body(lds.data(), p, a, tb, serial);
+    else
+      Core<WaveEmu, NB, false>::reset_body(lds.data(), p, a, tb, serial);
+  }
 }
 template <int NB>
 static void run_step(const Params &p, const uint8_t *cmds, int k) {
   std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad));
-  for (int a = 0; a < p.A; ++a) Core<WaveEmu, NB>::step_body(lds.data(), p, a, cmds, k);
+  for (int a = 0; a < p.A; ++a) {
+    if (hbm_plane(p.cells_pad))
+      Core<WaveEmu, NB, true>::step_body(lds.data(), p, a, cmds, k);
+    else
+      Core<WaveEmu, NB, false>::step_body(lds.data(), p, a, cmds, k);
+  }
 }
 
 static void run_observe(const Params &p, float *out) {
