@@ -102,6 +102,60 @@ def three_floor_map(rows, cols, wall_p=0.05, map_seed=7):
     return "".join(chars).encode("ascii"), portal
 
 
+def parse_floor_text(text, rows, cols):
+    """One `map/floorK.txt` of the reference, read the way gameplay::setup() does (gameplay.hpp:1249-1274): characters
+    are taken with `f >> c` (whitespace skipped), and a '^' or 'v' is followed by the number of the exit it leads to.
+    Returns (chars: str of rows*cols, portal: list[int])."""
+    chars, portal = [], []
+    i, n = 0, len(text)
+    while len(chars) < rows * cols:
+        while i < n and text[i].isspace():
+            i += 1
+        if i >= n:
+            raise ValueError("map text ends after %d of %d cells" % (len(chars), rows * cols))
+        c = text[i]
+        i += 1
+        idx = -1
+        if c in "^v":
+            while i < n and text[i].isspace():
+                i += 1
+            j = i
+            while j < n and (text[j].isdigit() or (j == i and text[j] == "-")):
+                j += 1
+            if j == i:
+                raise ValueError("portal entrance without an exit number at cell %d" % len(chars))
+            idx = int(text[i:j])
+            i = j
+        elif c not in "#.O":
+            c = "."  # setup() leaves any other character as an empty cell
+        chars.append(c)
+        portal.append(idx)
+    return "".join(chars), portal
+
+
+def format_floor_text(chars, portal, rows, cols):
+    """The inverse of parse_floor_text: the reference's text layout (one row per line, '^ k' / 'v k' entrances)."""
+    lines = []
+    for r in range(rows):
+        row = []
+        for c in range(cols):
+            ch = chars[r * cols + c]
+            row.append("%s %d " % (ch, portal[r * cols + c]) if ch in "^v" else ch)
+        lines.append("".join(row))
+    return "\n".join(lines) + "\n"
+
+
+def load_reference_maps(directory, floors=3, rows=30, cols=100):
+    """Reads map/floor1.txt .. floor<floors>.txt of a reference checkout (native dims gameplay.hpp:37)."""
+    import os
+    chars, portal = "", []
+    for k in range(floors):
+        c, p = parse_floor_text(open(os.path.join(directory, "floor%d.txt" % (k + 1))).read(), rows, cols)
+        chars += c
+        portal += p
+    return chars.encode("ascii"), portal
+
+
 class Workload:
     """Owns the ctypes Config and the buffers it points into."""
 

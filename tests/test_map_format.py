@@ -1,0 +1,36 @@
+"""The reference's map text format (map/floorK.txt, parser gameplay.hpp:1249-1274): parse, format, load a directory.
+The files written here are synthetic; pointing load_reference_maps() at a reference checkout's map/ works the same."""
+from oracle_lib import Oracle
+from emu_lib import Emu
+from strikeforce_amd import abi, config
+
+
+def test_parse_matches_the_reference_reader():
+    # "#^ 2 ^ 2 #" style rows: entrances carry their exit number, whitespace is free-form
+    text = "###^ 2 ^ 2 ###\n#..O...#\n#.v 0 ....#\n########\n"
+    chars, portal = config.parse_floor_text(text, 4, 8)
+    assert chars == "###^^###" "#..O...#" "#.v....#" "########"
+    assert portal[3] == 2 and portal[4] == 2 and portal[8 * 2 + 2] == 0
+    assert sum(1 for p in portal if p >= 0) == 3
+    assert config.parse_floor_text(config.format_floor_text(chars, portal, 4, 8), 4, 8) == (chars, portal)
+
+
+def test_three_floor_directory_round_trip_and_parity(tmp_path):
+    rows, cols = 30, 100  # the reference's N, M (gameplay.hpp:37)
+    m, p = config.three_floor_map(rows, cols, wall_p=0.06, map_seed=11)
+    per = rows * cols
+    for k in range(3):
+        (tmp_path / ("floor%d.txt" % (k + 1))).write_text(
+            config.format_floor_text(m[k * per:(k + 1) * per].decode(), p[k * per:(k + 1) * per], rows, cols))
+    m2, p2 = config.load_reference_maps(str(tmp_path))
+    assert m2 == m and p2 == p
+    cfg = config.make_config(2, rows, cols, floors=3, H=16, Z=24, B=64, P=16, mode=abi.MODE_SQUAD, level=3, n_agents=2)
+    w = config.Workload("native", cfg, m2, p2)
+    o, e = Oracle(w), Emu(w)
+    tb, sr = w.seeds()
+    o.reset(tb, sr), e.reset(tb, sr)
+    cmds, _ = config.bench_commands(2, 2, 300)
+    o.step_many(cmds), e.step_many(cmds)
+    assert (o.digest() == e.digest()).all()
+    d = o.dump(0)
+    assert {h.f for h in d.humans if h.alive} >= {0, 2}  # Squad: team-mates on floor 0, opponents on floor 2
