@@ -34,3 +34,30 @@ def test_three_floor_directory_round_trip_and_parity(tmp_path):
     assert (o.digest() == e.digest()).all()
     d = o.dump(0)
     assert {h.f for h in d.humans if h.alive} >= {0, 2}  # Squad: team-mates on floor 0, opponents on floor 2
+
+
+REF_MAP_DIR = "/root/reference/StrikeForce-client/map"
+
+
+def test_native_world_on_the_reference_maps_when_present():
+    """The shipped 3 x 30 x 100 world (map/floor1-3.txt: 6 exits, '^'/'v' entrances in the top border rows) with the
+    reference's level-10 account, Solo and Squad.  Reads the reference checkout, so it only runs where that exists
+    (never on the GPU box); the data is not copied."""
+    import os
+    import pytest
+    import fuzz_cases
+    if not os.path.isdir(REF_MAP_DIR):
+        pytest.skip("no reference checkout")
+    m, p = config.load_reference_maps(REF_MAP_DIR)
+    assert len(m) == 9000 and m.count(b"O") == 6
+    for mode, agents in ((abi.MODE_SOLO, 1), (abi.MODE_SQUAD, 3)):
+        cfg = config.make_config(2, 30, 100, floors=3, H=64, Z=64, B=256, P=32, mode=mode, level=4, n_agents=agents,
+                                 player_tokens=fuzz_cases.ACCOUNT_1)
+        w = config.Workload("native", cfg, m, p)
+        o, e = Oracle(w), Emu(w)
+        tb, sr = w.seeds()
+        o.reset(tb, sr), e.reset(tb, sr)
+        cmds, _ = config.bench_commands(2, agents, 500)
+        o.step_many(cmds), e.step_many(cmds)
+        assert (o.digest() == e.digest()).all()
+        assert (o.results() == e.results()).all()
