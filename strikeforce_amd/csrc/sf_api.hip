@@ -87,6 +87,7 @@ __global__ __launch_bounds__(OBS_THREADS, 4) void k_observe(Params p, float *out
   __shared__ uint32_t list_idx[OBS_LIST_MAX];
   __shared__ float list_val[OBS_LIST_MAX];
   __shared__ uint32_t nzmap[OBS_W2];  // one bit per output float: non-zero (30752 bits)
+  __shared__ uint32_t cmask[OBS_CLASS_RECS];  // non-zero channels of each class record
   __shared__ uint32_t list_n, rec_n, spill_n;
   const int a = (int)blockIdx.x / p.n_agents, g = (int)blockIdx.x % p.n_agents;
   const int tid = (int)threadIdx.x;
@@ -141,55 +142,68 @@ __global__ __launch_bounds__(OBS_THREADS, 4) void k_observe(Params p, float *out
   }
   lds_barrier();
   // ---- pass 3 ----------------------------------------------------------------------------------------------
+  // items 0..7 are the shared class records (a pseudo-cell with that class's flag byte and nothing on it), items
+  // 8.. are the window cells; one instantiation of obs_cell_emit serves both
   const Tables &tab = *p.tab;
-  if (tid < OBS_CLASS_RECS) {  // the shared records: constants only, no pow (host table)
-#pragma unroll
-    for (int k = 0; k < SF_OBS_CHANNELS; ++k) rec[tid][k] = 0.f;
-    obs_cell_emit(v, obs_class_flags(tid), 0, 0u, pteam, [&](int k, float x) {
-      float y;
-      if (!obs_map_fast(tab, x, y)) y = obs_map(x);
-      rec[tid][k] = y;
-    });
-  }
-  for (int w = tid; w < OBS_W2; w += OBS_THREADS) {
-    const uint32_t fl = wfl[w], oc = occ[w];
+  for (int item = tid; item < OBS_CLASS_RECS + OBS_W2; item += OBS_THREADS) {
+    const bool is_class = item < OBS_CLASS_RECS;
+    const int w = item - OBS_CLASS_RECS;
+    const uint32_t fl = is_class ? obs_class_flags(item) : (uint32_t)wfl[w];
+    const uint32_t oc = is_class ? 0u : occ[w];
     if (fl == 0u && oc == 0u) continue;  // '.' with nothing on it
-    const int cls = oc == 0u ? obs_class_of(fl) : -1;
-    if (cls >= 0) {  // plain static cell: shared record; only its non-zero bits are per cell
-      slot[w] = (uint8_t)cls;
-      obs_cell_emit(v, fl, 0, 0u, pteam, [&](int k, float) {
-        const uint32_t bit = (uint32_t)(k * OBS_W2 + w);
-        atomicOr(&nzmap[bit >> 5], 1u << (bit & 31u));
-      });
-      continue;
-    }
-    const uint32_t r = atomicAdd(&rec_n, 1u);
-    if (r < (uint32_t)OBS_REC_MAX) {
-      slot[w] = (uint8_t)r;
-#pragma unroll
-      for (int k = 0; k < SF_OBS_CHANNELS; ++k) rec[r][k] = 0.f;
-      obs_cell_emit(v, fl, wdmg[w], oc, pteam, [&](int k, float x) {
-        float y;
-        const bool fast = obs_map_fast(tab, x, y);
-        if (fast && y == 0.f) return;
-        const uint32_t bit = (uint32_t)(k * OBS_W2 + w);
-        atomicOr(&nzmap[bit >> 5], 1u << (bit & 31u));
-        if (fast) {
-          rec[r][k] = y;
-        } else {
-          const uint32_t q = atomicAdd(&list_n, 1u);
-          if (q < (uint32_t)OBS_LIST_MAX)
-            list_idx[q] = r * SF_OBS_CHANNELS + (uint32_t)k, list_val[q] = x;
-          else
-            rec[r][k] = obs_map(x);
-        }
-      });
+    uint32_t r;
+    if (is_class) {
+      r = (uint32_t)item;
     } else {
-      atomicAdd(&spill_n, 1u);  // more non-empty cells than records: written after the stream, see below
+      const int cls = oc == 0u ? obs_class_of(fl) : -1;
+      if (cls >= 0) {  // plain static cell: shared record, its non-zero bits are set after the barrier
+        slot[w] = (uint8_t)cls;
+        continue;
+      }
+      r = atomicAdd(&rec_n, 1u);
+      if (r >= (uint32_t)OBS_REC_MAX) {
+        atomicAdd(&spill_n, 1u);  // more non-empty cells than records: written after the stream, see below
+        continue;
+      }
+      slot[w] = (uint8_t)r;
+    }
+#pragma unroll
+    for (int k = 0; k < SF_OBS_CHANNELS; ++k) rec[r][k] = 0.f;
+    uint32_t mask = 0u;
+    obs_cell_emit(v, fl, is_class ? 0 : wdmg[w], oc, pteam, [&](int k, float x) {
+      float y;
+      const bool fast = obs_map_fast(tab, x, y);
+      if (fast && y == 0.f) return;
+      mask |= 1u << k;
+      if (fast) {
+        rec[r][k] = y;
+      } else {
+        const uint32_t q = atomicAdd(&list_n, 1u);
+        if (q < (uint32_t)OBS_LIST_MAX)
+          list_idx[q] = r * SF_OBS_CHANNELS + (uint32_t)k, list_val[q] = x;
+        else
+          rec[r][k] = obs_map(x);
+      }
+    });
+    if (is_class) {
+      cmask[item] = mask;
+    } else {
+      for (uint32_t m = mask; m; m &= m - 1u) {
+        const uint32_t bit = (uint32_t)__builtin_ctz(m) * OBS_W2 + (uint32_t)w;
+        atomicOr(&nzmap[bit >> 5], 1u << (bit & 31u));
+      }
     }
   }
   lds_barrier();
-  // ---- pass 3b ---------------------------------------------------------------------------------------------
+  for (int w = tid; w < OBS_W2; w += OBS_THREADS) {  // plain static cells: the class's non-zero channels
+    const uint32_t sl = slot[w];
+    if (sl >= (uint32_t)OBS_CLASS_RECS) continue;
+    for (uint32_t m = cmask[sl]; m; m &= m - 1u) {
+      const uint32_t bit = (uint32_t)__builtin_ctz(m) * OBS_W2 + (uint32_t)w;
+      atomicOr(&nzmap[bit >> 5], 1u << (bit & 31u));
+    }
+  }
+  // ---- pass 3b (same barrier interval: both only consume pass 3's results) -------------------------------------
   {
     const uint32_t n = list_n < (uint32_t)OBS_LIST_MAX ? list_n : (uint32_t)OBS_LIST_MAX;
     for (uint32_t i = (uint32_t)tid; i < n; i += OBS_THREADS) (&rec[0][0])[list_idx[i]] = obs_map(list_val[i]);

@@ -16,15 +16,25 @@ def _digests(sim, w):
     half = w.steps // 2
     sim.step_many(cmds[:half])
     out.append(sim.digest().tolist())
+    obs = sim.observe()  # mid-run, so that agents are alive and things are in view
     sim.step_many(cmds[half:])
     out.append(sim.digest().tolist())
-    return out, sim.results().tolist()
+    return out, sim.results().tolist(), obs
+
+
+def _same_obs(x, y, max_ulp):
+    import numpy as np
+    assert x.shape == y.shape and np.array_equal(x == 0, y == 0)
+    d = np.abs(x.view(np.int32).astype(np.int64) - y.view(np.int32).astype(np.int64))
+    assert d.max() <= max_ulp, "max ulp %d" % d.max()
 
 
 @pytest.mark.parametrize("seed", fuzz_cases.SEEDS)
 def test_fuzz_emulated_core_matches_oracle(seed):
     w = fuzz_cases.make_case(seed)
-    assert _digests(Oracle(w), w) == _digests(Emu(w), w)
+    a, b = _digests(Oracle(w), w), _digests(Emu(w), w)
+    assert a[:2] == b[:2]
+    _same_obs(a[2], b[2], 0)
 
 
 @pytest.mark.gpu
@@ -39,4 +49,6 @@ def test_fuzz_gpu_matches_oracle(seed):
                 self.step(np.ascontiguousarray(c))
 
     w = fuzz_cases.make_case(seed)
-    assert _digests(Oracle(w), w) == _digests(Gpu(w), w)
+    a, b = _digests(Oracle(w), w), _digests(Gpu(w), w)
+    assert a[:2] == b[:2]
+    _same_obs(a[2], b[2], 1)  # ocml pow vs glibc pow: <= 1 float ulp
