@@ -98,7 +98,7 @@ __global__ __launch_bounds__(OBS_THREADS, 4) void k_observe(Params p, float *out
   const uint32_t hf = gptr(p.hum)[((size_t)HW_FLAGS * p.A + a) * p.H + g];
   const uint32_t center = gptr(p.hum)[((size_t)HW_POS * p.A + a) * p.H + g];
   if ((hf & (HF_ALIVE | HF_CTRL)) != (HF_ALIVE | HF_CTRL)) {  // no observer: all zero (uniform over the workgroup)
-    for (int i = tid; i < SF_OBS_FLOATS / 4; i += OBS_THREADS) o4[i] = (f32x4)(0.f);
+    for (int i = tid; i < SF_OBS_FLOATS / 4; i += OBS_THREADS) __builtin_nontemporal_store((f32x4)(0.f), &o4[i]);
     return;
   }
   const int nh = HW_WORDS * p.H, nz = ZW_WORDS * p.Z, nb = BW_WORDS * p.B;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(OBS_THREADS, 4) void k_observe(Params p, float *out
         if (++w == (uint32_t)OBS_W2) w = 0u, ++k;
       }
     }
-    o4[i] = val;
+    __builtin_nontemporal_store(val, &o4[i]);  // streamed once, never re-read by this kernel
   }
   if (spill_n) {  // a window crowded beyond OBS_REC_MAX cells (never in the BASELINE configs): direct, slower
     __syncthreads();  // the streamed zeros of those cells are complete before they are overwritten
