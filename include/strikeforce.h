@@ -95,7 +95,10 @@ typedef struct sf_config {
   int32_t cap_humans, cap_zombies, cap_bullets, cap_portals, cap_chests; /* gameplay.hpp:37 H, Z, B, (B), C */
   int32_t mode;             /* SF_MODE_* */
   int32_t level;            /* 1..10, gameplay.hpp:459 L */
-  int32_t n_agents;         /* humans commanded through sf_step; agent 0 is the reference's `ind` */
+  int32_t n_agents;         /* humans commanded through sf_step */
+  int32_t ind;              /* which of them is the reference's `ind` (gameplay.hpp:39): the player whose death ends the
+                               episode and whose team the kill/loot counters follow.  0 except in lock-step Battle matches,
+                               where the match server assigns it (server.cpp:243-246) */
   int32_t agent_team[SF_MAX_AGENTS]; /* BATTLE mode teams (server.cpp:239-246); ignored otherwise */
   int32_t auto_reset;       /* re-seed (tb += reseed_stride) and restart an arena when its episode ends */
   int32_t reseed_stride;    /* 0 -> arenas; multi-GPU runs pass the global arena count so that shards never reuse a seed */

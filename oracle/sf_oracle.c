@@ -1256,6 +1256,7 @@ static int o_validate(const sf_config *c) {
   if (c->n_agents < 1 || c->n_agents > SF_MAX_AGENTS || c->n_agents > c->cap_humans) return 0;
   if (c->level < 1 || c->level > 10) return 0;
   if (c->mode == SF_MODE_SQUAD && c->cap_humans < 10) return 0;
+  if (c->ind < 0 || c->ind >= c->n_agents || (c->ind != 0 && c->mode != SF_MODE_BATTLE)) return 0;
   return 1;
 }
 
@@ -1266,7 +1267,7 @@ sfo_env *sfo_create(const sf_config *cfg) {
   e->F = cfg->floors, e->N = cfg->rows, e->M = cfg->cols;
   e->H = cfg->cap_humans, e->Z = cfg->cap_zombies, e->B = cfg->cap_bullets, e->P = cfg->cap_portals;
   e->C = cfg->cap_chests;
-  e->ind = 0;
+  e->ind = cfg->ind;
   const int cells = e->F * e->N * e->M;
   e->map_chars = (char *)malloc((size_t)cells);
   memcpy(e->map_chars, cfg->map, (size_t)cells);

@@ -80,6 +80,7 @@ class Config(C.Structure):
         ("mode", C.c_int32),
         ("level", C.c_int32),
         ("n_agents", C.c_int32),
+        ("ind", C.c_int32),
         ("agent_team", C.c_int32 * MAX_AGENTS),
         ("auto_reset", C.c_int32),
         ("reseed_stride", C.c_int32),

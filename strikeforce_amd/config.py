@@ -181,13 +181,14 @@ class Workload:
 
 def make_config(arenas, rows, cols, floors=1, H=1, Z=16, B=32, P=8, chests=9000, mode=abi.MODE_SOLO, level=1,
                 n_agents=1, teams=None, auto_reset=1, player_tokens=None, npc_tokens=None, device=0,
-                timer_frames=0, reseed_stride=0):
+                timer_frames=0, reseed_stride=0, ind=0):
     cfg = abi.Config()
     cfg.abi_version = abi.SF_ABI_VERSION
     cfg.arenas = arenas
     cfg.floors, cfg.rows, cfg.cols = floors, rows, cols
     cfg.cap_humans, cfg.cap_zombies, cfg.cap_bullets, cfg.cap_portals, cfg.cap_chests = H, Z, B, P, chests
     cfg.mode, cfg.level, cfg.n_agents = mode, level, n_agents
+    cfg.ind = ind
     for i in range(abi.MAX_AGENTS):
         cfg.agent_team[i] = (teams[i] if teams and i < len(teams) else i + 1)
     cfg.auto_reset = auto_reset

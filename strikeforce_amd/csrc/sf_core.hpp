@@ -233,8 +233,8 @@ struct Core {
     uint64_t fr = ~W::ballot((S.zpos & ZF_ALIVE) != 0u) & capmask(p.Z);
     return fr ? W::ctz64(fr) : -1;
   }
-  static SF_DEV int h_ind(const Arena &S, const Params &p) {  // skips `ind` (= slot 0) and remote slots
-    uint64_t fr = ~W::ballot((S.hfl & (HF_ALIVE | HF_REMOTE)) != 0u) & capmask(p.H) & ~1ull;
+  static SF_DEV int h_ind(const Arena &S, const Params &p) {  // skips `ind` and remote slots
+    uint64_t fr = ~W::ballot((S.hfl & (HF_ALIVE | HF_REMOTE)) != 0u) & capmask(p.H) & ~(1ull << p.ind);
     return fr ? W::ctz64(fr) : -1;
   }
   static SF_DEV int p_ind(const Arena &S, const Params &p) {
@@ -544,13 +544,13 @@ struct Core {
   // cell's designated bullet, so the two slot-ordered sweeps reduce to: (1) humans already at Hp <= 0 die
   // (lane-parallel); (2) one wave-uniform pass over designated bullets that share a cell with a live
   // character.  All cross-entity effects are additive (owner damage/effect/kills, loot, kill counters).
-  static SF_DEV void hits(Arena &S) {
+  static SF_DEV void hits(Arena &S, const Params &p) {
     {
       const P dying = ((S.hfl & HF_ALIVE) != 0u) & W::le0(S.hhp);                  // G:641-645
       // s[0] = (human == &hum[ind]); deleteAgent() only for i != ind  G:643,648-649
-      S.hfl = W::select(dying, W::select(W::lane() == 0u, S.hfl & ~HF_ALIVE, S.hfl & ~(HF_ALIVE | HF_CTRL | HF_OCC)), S.hfl);
+      S.hfl = W::select(dying, W::select(W::lane() == (uint32_t)p.ind, S.hfl & ~HF_ALIVE, S.hfl & ~(HF_ALIVE | HF_CTRL | HF_OCC)), S.hfl);
     }
-    const uint32_t my_team = (uint32_t)h_team(W::readlane(S.hfl, 0u));
+    const uint32_t my_team = (uint32_t)h_team(W::readlane(S.hfl, (uint32_t)p.ind));
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       uint64_t m = W::ballot((S.ba[j] & BA_REF) != 0u);
@@ -580,10 +580,10 @@ struct Core {
             add_lane(S.hef, (uint32_t)(owner - 1), eff);
           }
           if (hp <= 0) {
-            W::setlane(S.hfl, (uint32_t)hv, hv == 0 ? (vfl & ~HF_ALIVE) : (vfl & ~(HF_ALIVE | HF_CTRL | HF_OCC)));
+            W::setlane(S.hfl, (uint32_t)hv, hv == p.ind ? (vfl & ~HF_ALIVE) : (vfl & ~(HF_ALIVE | HF_CTRL | HF_OCC)));
             if (owner && owner_team == my_team && vteam != my_team) {
               ++S.tkills, S.loot += 100;
-              if (owner == 1) S.loot += 900, ++S.kills;
+              if (owner == p.ind + 1) S.loot += 900, ++S.kills;
             }
             if (cross) add_lane(S.hk, (uint32_t)(owner - 1), 1);
           }
@@ -601,7 +601,7 @@ struct Core {
             if (owner && owner_team == my_team) {
               const int pts = 500 + ((zp & ZF_SUPER) ? 250 : 0);
               ++S.tkills, S.loot += pts / 10;
-              if (owner == 1) S.loot += pts * 9 / 10, ++S.kills;
+              if (owner == p.ind + 1) S.loot += pts * 9 / 10, ++S.kills;
             }
             if (owner) add_lane(S.hk, (uint32_t)(owner - 1), 1);
           }
@@ -866,9 +866,9 @@ struct Core {
     const uint64_t alive = W::ballot((S.hfl & HF_ALIVE) != 0u) & capmask(p.H);
     // get_command G:929-937, slot order, for i != ind: remote keep theirs, rnpc draw, agents keep theirs, others '+'
     {
-      const P ext = ((S.hfl & (HF_REMOTE | HF_CTRL)) != 0u) | (W::lane() == 0u);
+      const P ext = ((S.hfl & (HF_REMOTE | HF_CTRL)) != 0u) | (W::lane() == (uint32_t)p.ind);
       S.hcmd = W::select(ext, S.hcmd, V((uint32_t)'+'));
-      uint64_t m = alive & ~1ull & W::ballot((S.hfl & (HF_RNPC | HF_REMOTE)) == HF_RNPC);
+      uint64_t m = alive & ~(1ull << p.ind) & W::ballot((S.hfl & (HF_RNPC | HF_REMOTE)) == HF_RNPC);
       while (m) {
         const uint32_t i = (uint32_t)W::ctz64(m);
         m &= m - 1ull;
@@ -895,9 +895,9 @@ struct Core {
     return W::ballot(((S.hfl & HF_ALIVE) != 0u) & (team != 0u) & (team != my_team)) == 0ull;
   }
   static SF_DEV int check_end(const Arena &S, const Params &p) {
-    const uint32_t my_team = (uint32_t)h_team(W::readlane(S.hfl, 0u));
+    const uint32_t my_team = (uint32_t)h_team(W::readlane(S.hfl, (uint32_t)p.ind));
     if (p.mode == SF_MODE_BATTLE && rivals_are_dead(S, my_team)) return SF_WON;
-    if ((int32_t)W::readlane(S.hhp, 0u) <= 0) return SF_DIED;
+    if ((int32_t)W::readlane(S.hhp, (uint32_t)p.ind) <= 0) return SF_DIED;
     if (p.mode == SF_MODE_TIMER) {
       if (S.frame - 1 >= p.timer_lim) return S.kills < p.level * 5 ? SF_TIME_LOST : SF_TIME_WON;
       return SF_RUNNING;
@@ -969,7 +969,7 @@ struct Core {
       int prof = 0, team = 1;
       uint32_t q = pos_pack(0, 1, 1), fl = HF_CTRL;
       if (p.mode == SF_MODE_BATTLE) {
-        q = POS_NONE, team = p.tab->teams[i], fl = HF_CTRL | (i ? HF_REMOTE : 0u);
+        q = POS_NONE, team = p.tab->teams[i], fl = HF_CTRL | (i != p.ind ? HF_REMOTE : 0u);
       } else if (p.mode == SF_MODE_SQUAD) {
         prof = i ? 1 : 0;
         team = i < 5 ? 1 : 2;
@@ -1008,7 +1008,7 @@ struct Core {
         human_action(S, lds, p, a);
       }
       update_tmp(S, lds, p, a);
-      hits(S);
+      hits(S, p);
       ++S.frame;  // updmap G:489-495 clears render-only bits
       update_bull(S, lds, p);
     }

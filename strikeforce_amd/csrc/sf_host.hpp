@@ -97,6 +97,8 @@ inline int validate(const sf_config *c) {
   if (c->cap_portals < 1 || c->cap_portals > SF_MAX_PORTALS) return fail(SF_ERR_ARG, "cap_portals must be 1..64");
   if (c->cap_chests < 0) return fail(SF_ERR_ARG, "cap_chests < 0");
   if (c->reseed_stride < 0) return fail(SF_ERR_ARG, "reseed_stride < 0");
+  if (c->ind < 0 || c->ind >= c->n_agents || (c->ind != 0 && c->mode != SF_MODE_BATTLE))
+    return fail(SF_ERR_ARG, "ind must be 0, or an agent slot of a Battle match");
   if (c->n_agents < 1 || c->n_agents > SF_MAX_AGENTS || c->n_agents > c->cap_humans)
     return fail(SF_ERR_ARG, "n_agents must be 1..min(16, cap_humans)");
   if (c->level < 1 || c->level > 10) return fail(SF_ERR_ARG, "level must be 1..10");
@@ -189,6 +191,7 @@ struct Env {
     p.reseed = cfg.reseed_stride > 0 ? cfg.reseed_stride : cfg.arenas;
     p.timer_lim = cfg.level * (cfg.timer_frames_per_level > 0 ? cfg.timer_frames_per_level : 7500);
     p.squad_floor = cfg.floors > 2 ? 2 : cfg.floors - 1;
+    p.ind = cfg.ind;
     NB = nb_for(p.B);
     if (!hbm_plane(p.cells_pad) && lds_bytes_for(p.cells_pad) > rt.max_lds())
       return fail(SF_ERR_ARG, "map does not fit the LDS flag plane");

@@ -85,6 +85,7 @@ struct Params {
   int32_t A, F, N, M, cells, cells_pad;
   int32_t H, Z, B, P, C;
   int32_t mode, level, n_agents, auto_reset, reseed, timer_lim, squad_floor;
+  int32_t ind;     // the human slot this process plays (`ind`, gameplay.hpp:39); 0 except in Battle matches
   const Tables *tab;
   uint32_t *hum;   // [HW_WORDS][A][H]
   uint32_t *zom;   // [ZW_WORDS][A][Z]

@@ -161,6 +161,13 @@ class ArenaBatch:
                                       pidx.ctypes.data_as(C.POINTER(C.c_int32))), "sf_dump_arena")
         return hdr, list(hs), list(zs), list(bs), list(ps), flags, dmg, pidx
 
+    def dump(self, arena):
+        """dump_raw() as an object with named fields (hdr, humans, zombies, bullets, portals, flags, dmg, pidx)."""
+        import types
+        hdr, hs, zs, bs, ps, flags, dmg, pidx = self.dump_raw(arena)
+        return types.SimpleNamespace(hdr=hdr, humans=hs, zombies=zs, bullets=bs, portals=ps, flags=flags, dmg=dmg,
+                                     pidx=pidx)
+
     def kernel_time(self, enable=True):
         """(ms, launches) of the step kernels since the last call, from HIP events on the launch stream."""
         ms, n = C.c_float(0), C.c_int32(0)
