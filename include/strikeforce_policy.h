@@ -1,0 +1,93 @@
+/* strikeforce_policy.h — C-ABI of the batched on-device policy network.
+ *
+ * The reference evaluates its bot network once per agent per tick on the host with libtorch, batch 1
+ * (StrikeForce-client/bots/bot-0.5/Agent.hpp:178-214 predict(), Modules.hpp:54-179 AgentModel).  This
+ * library evaluates the same network for every agent of an arena batch in one pass on the GPU, reading
+ * the observation buffer sf_observe_device() wrote and producing the command chars sf_step_device()
+ * consumes, so the 123 KB/agent observation never leaves HBM.  Arithmetic is f32 end to end (f32-input
+ * MFMA, f32 accumulate); every agent keeps its own recurrent state exactly as one reference `Agent`
+ * object does.  Inference only: the PPO learner (Agent.hpp:270-420) is out of scope.
+ *
+ * Same conventions as strikeforce.h: plain pointers and sizes, 0 = success, sf_last_error() for text,
+ * no CPU path (SF_ERR_DEVICE without a GPU).
+ */
+#ifndef STRIKEFORCE_POLICY_H
+#define STRIKEFORCE_POLICY_H
+
+#include <stdint.h>
+
+#include "strikeforce.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_POLICY_ABI_VERSION 1
+#define SF_POLICY_HIDDEN 160   /* hidden_size   Modules.hpp:83,144 */
+#define SF_POLICY_ACTIONS 9    /* num_actions   Modules.hpp:83,144; action string "+xzqeawsd" Custom.hpp:162 */
+#define SF_POLICY_CONVS 4      /* GameCNN(num_channels, hidden_size, 4, grid_x)  Modules.hpp:86 */
+#define SF_POLICY_RES_LAYERS 3 /* LAYER_INDEX   Modules.hpp:28 */
+#define SF_POLICY_POV (5 * SF_OBS_CHANNELS + SF_POLICY_ACTIONS) /* 169: the 5 centre cells + last action  Modules.hpp:115-122 */
+
+/* Host pointers to the parameters, in the layouts torch uses for the reference's modules (row-major,
+ * f32).  Names follow the reference's register_module() names. */
+typedef struct sf_policy_weights {
+  int32_t abi_version;
+  /* backbone.cnn.conv{i}.weight: conv0 [160][32][3][3], conv1..3 [160][160][3][3]; stride 2, no padding, no
+   * bias (Modules.hpp:58-64) */
+  const float *conv_w[SF_POLICY_CONVS];
+  /* backbone.gru{g}.weight_ih_l0 / weight_hh_l0 [480][160], bias_ih_l0 / bias_hh_l0 [480]; gate order r,z,n
+   * (torch::nn::GRU, Modules.hpp:87,91) */
+  const float *gru_w_ih[2], *gru_w_hh[2], *gru_b_ih[2], *gru_b_hh[2];
+  /* backbone.combined_processor.0.weight [160][2*160+9], .bias [160]  (Modules.hpp:88-90) */
+  const float *comb_w, *comb_b;
+  /* value.0.lin{i}.weight [160][160], .bias [160]; value.1.weight [1][160], .bias [1]   (Modules.hpp:147-149) */
+  const float *value_res_w[SF_POLICY_RES_LAYERS], *value_res_b[SF_POLICY_RES_LAYERS], *value_w, *value_b;
+  /* policy.0.lin{i}.weight, .bias; policy.1.weight [9][160], .bias [9]                 (Modules.hpp:150-152) */
+  const float *policy_res_w[SF_POLICY_RES_LAYERS], *policy_res_b[SF_POLICY_RES_LAYERS], *policy_w, *policy_b;
+} sf_policy_weights;
+
+typedef struct sf_policy sf_policy;
+
+/* new AgentModel + load of its parameters (Agent.hpp:77-110), for `max_agents` independent agents (each has
+ * its own h_state[2] and action_input, Modules.hpp:81).  Memory starts as after reset_memory(). */
+int sf_policy_create(const sf_policy_weights *w, int32_t max_agents, int32_t device, sf_policy **out);
+void sf_policy_destroy(sf_policy *p);
+
+/* Backbone::reset_memory() (Modules.hpp:95-100) for the agents whose byte in d_mask (device, one per agent) is
+ * non-zero; NULL resets every agent.  Call it with the done flags when an arena restarts: the reference
+ * builds a new Agent per game (Custom.hpp prepare()). */
+int sf_policy_reset_memory(sf_policy *p, const uint8_t *d_mask);
+
+/* AgentModel::forward (Modules.hpp:106-134,169-178) for agents [0, agents): d_obs is the device buffer of
+ * sf_observe_device ([agents][32][31][31] f32); writes d_probs [agents][9] (softmax + 1e-8) and d_value [agents]
+ * (sigmoid), and advances every agent's h_state. */
+int sf_policy_forward(sf_policy *p, const float *d_obs, int32_t agents, float *d_probs, float *d_value);
+
+/* The tail of Agent::predict() + Agent::update() (Agent.hpp:200-222): v[0] = 0.5, v[i>0] *= 0.5/(1-v[0]+1e-5),
+ * draw from discrete_distribution(v) (greedy != 0: arg-max of v instead), store the one-hot as the agent's
+ * action_input (update_actions) and write command char action_string[a] to d_cmd[agent] (gameplay::bot,
+ * Custom.hpp:160-163).  The reference seeds std::mt19937 from std::random_device per call, so only the
+ * distribution is specified; here draw i of agent a is a counter-based hash of (seed, a, i).
+ * d_action (device, int32 per agent) may be NULL. */
+int sf_policy_act(sf_policy *p, const float *d_probs, int32_t agents, const char *action_string, uint64_t seed,
+                  int32_t greedy, uint8_t *d_cmd, int32_t *d_action);
+
+/* Read/write one agent's recurrent state for tests: h [2][160] and the action one-hot [9] (host buffers). */
+int sf_policy_get_memory(sf_policy *p, int32_t agent, float *h, float *action_input);
+int sf_policy_set_memory(sf_policy *p, int32_t agent, const float *h, const float *action_input);
+
+int sf_policy_set_stream(sf_policy *p, void *hip_stream);
+int sf_policy_synchronize(sf_policy *p);
+
+/* Device time of the matrix kernels of the forward passes since the last call (HIP events on the library's
+ * stream): *ms = summed duration of the MFMA GEMM launches, *flop = their algorithmic flop count
+ * (2*M*N*K each), *launches = how many. */
+int sf_policy_kernel_time(sf_policy *p, int32_t enable, float *ms, double *flop, int32_t *launches);
+
+int sf_policy_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRIKEFORCE_POLICY_H */

@@ -12,9 +12,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstrikeforce_amd.so")
-SOURCES = ["sf_api.hip"]
-DEPS = ["sf_api.hip", "sf_core.hpp", "sf_obs.hpp", "sf_host.hpp", "sf_types.hpp", "wave_gfx950.hpp",
-        os.path.join("..", "..", "include", "strikeforce.h")]
+SOURCES = ["sf_api.hip", "sf_policy.hip"]
+DEPS = ["sf_api.hip", "sf_policy.hip", "sf_core.hpp", "sf_obs.hpp", "sf_host.hpp", "sf_types.hpp", "wave_gfx950.hpp",
+        os.path.join("..", "..", "include", "strikeforce.h"),
+        os.path.join("..", "..", "include", "strikeforce_policy.h")]
 
 
 def stale():

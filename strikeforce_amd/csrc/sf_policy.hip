@@ -1,0 +1,721 @@
+// sf_policy.hip — batched on-device evaluation of the reference's bot network.
+//
+// What is computed, per agent, is AgentModel::forward of StrikeForce-client/bots/bot-0.5/Modules.hpp:54-179:
+//   GameCNN (4x Conv2d 3x3 stride 2, no bias, no activation; 32->160 channels; 31->15->7->3->1)   :54-72
+//   Backbone: L1-style normalisations x*160/(sum|x|+1e-8), gru0, "pov" (5 centre cells x 32 channels + last
+//   action one-hot), Linear(329->160), gru1 with a residual                                        :106-134
+//   heads: ResB(160, 3) + Linear(160->9) -> softmax + 1e-8; ResB + Linear(160->1) -> sigmoid         :30-49,169-178
+// The reference runs it with batch 1 on the host; here a "row" is one agent and all matrix work is f32 MFMA
+// (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-for-bit a k-ordered fmaf chain), so results differ from
+// libtorch only by summation order.
+//
+// Kernels
+//   k_gemm<WAVES, MODE>   C[M][N] = A[M][K] * W[N][K]^T (+ bias), LDS-tiled, 32 rows x 160 columns per wave
+//                         (5 accumulator tiles of 32x32), BK = 16, register prefetch + double-buffered LDS.
+//                         MODE selects how a row of A is addressed: a dense row, or the im2col row of a 3x3/stride-2
+//                         convolution gathered on the fly from an NHWC activation (conv1..3) or from the NCHW
+//                         observation buffer (conv0).  Activations between the convolutions are kept NHWC, which is
+//                         simply the row-major C of the previous GEMM; the host permutes conv1..3's weights to the
+//                         matching (ky, kx, cin) K-order once at load time.
+//   k_*                   one wavefront per agent row for the 160-wide normalisations, the GRU gate math, the
+//                         residual blocks' relu+skip and the two heads.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/strikeforce_policy.h"
+#include "sf_host.hpp"
+
+namespace sfp {
+
+using sf::fail;
+
+constexpr int HID = SF_POLICY_HIDDEN;    // 160
+constexpr int ACT = SF_POLICY_ACTIONS;   // 9
+constexpr int G3 = 3 * HID;              // 480 gate rows r,z,n
+constexpr int OBS_C = SF_OBS_CHANNELS;   // 32
+constexpr int OBS_W = SF_OBS_WINDOW;     // 31
+constexpr int OBS_F = SF_OBS_FLOATS;     // 30752
+constexpr int POV = SF_POLICY_POV;       // 169
+constexpr int COMB = 2 * HID + ACT;      // 329 inputs of combined_processor
+constexpr int COMB_PAD = 336;            // padded to a multiple of the GEMM's K tile
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { MODE_DENSE = 0, MODE_NHWC = 1, MODE_NCHW = 2 };
+
+struct Gemm {
+  const float *A;
+  const float *W;     // [N][K] row-major
+  const float *bias;  // [N] or null
+  float *C;           // [M][ldc]
+  int M, N, K;        // K % 16 == 0, N % 160 == 0
+  int lda, ldc;
+  int S, Cin, So;     // convolution modes: input side, input channels, output side
+};
+
+constexpr int BN = 160, BK = 16, LD = BK + 1;
+
+__device__ inline f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+template <int WAVES, int MODE>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm(Gemm g) {
+  constexpr int T = WAVES * 64, BM = WAVES * 32;
+  constexpr int RP = T / 4;                    // rows covered by one pass of float4 loads
+  constexpr int AJ = BM / RP;                  // = 2
+  constexpr int BJ = (BN + RP - 1) / RP;       // 3, 5 or 10
+  constexpr int SJ = BK / (T / BM);            // scalar (NCHW) loads per thread = 8
+  __shared__ float As[2][BM * LD];
+  __shared__ float Bs[2][BN * LD];
+
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int KT = g.K / BK;
+
+  // ---- where this thread's share of the A tile comes from ----
+  const float *arow[AJ];
+  const float *acol = nullptr;  // NCHW: one row per thread
+  if (MODE == MODE_NCHW) {
+    int m = m0 + (t % BM);
+    if (m >= g.M) m = g.M - 1;
+    const int so2 = g.So * g.So;
+    const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
+    acol = g.A + (size_t)b * g.Cin * g.S * g.S + (size_t)(2 * oy) * g.S + 2 * ox;
+  } else {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      int m = m0 + t / 4 + j * RP;
+      if (m >= g.M) m = g.M - 1;
+      if (MODE == MODE_DENSE) {
+        arow[j] = g.A + (size_t)m * g.lda + (t & 3) * 4;
+      } else {
+        const int so2 = g.So * g.So;
+        const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
+        arow[j] = g.A + ((size_t)(b * g.S + 2 * oy) * g.S + 2 * ox) * g.Cin + (t & 3) * 4;
+      }
+    }
+  }
+  const float *brow[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    int n = t / 4 + j * RP;
+    if (n >= BN) n = BN - 1;
+    brow[j] = g.W + (size_t)(n0 + n) * g.K + (t & 3) * 4;
+  }
+
+  f32x4 ra[AJ], rb[BJ];
+  float rs[SJ];
+
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+    if (MODE == MODE_NCHW) {
+      const int ss = g.S * g.S;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        const int k = k0 + t / BM + j * (T / BM);
+        const int cin = k / 9, tap = k - cin * 9, ky = tap / 3, kx = tap - ky * 3;
+        rs[j] = acol[(size_t)cin * ss + ky * g.S + kx];
+      }
+    } else {
+      int off = k0;
+      if (MODE == MODE_NHWC) {
+        const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin, ky = tap / 3, kx = tap - ky * 3;
+        off = (ky * g.S + kx) * g.Cin + c0;
+      }
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) ra[j] = ldg4(arow[j] + off);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) rb[j] = ldg4(brow[j] + k0);
+  };
+  auto lstore = [&](int buf) {
+    if (MODE == MODE_NCHW) {
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) As[buf][(t % BM) * LD + t / BM + j * (T / BM)] = rs[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        float *d = &As[buf][(t / 4 + j * RP) * LD + (t & 3) * 4];
+        d[0] = ra[j].x, d[1] = ra[j].y, d[2] = ra[j].z, d[3] = ra[j].w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int n = t / 4 + j * RP;
+      if (n < BN) {
+        float *d = &Bs[buf][n * LD + (t & 3) * 4];
+        d[0] = rb[j].x, d[1] = rb[j].y, d[2] = rb[j].z, d[3] = rb[j].w;
+      }
+    }
+  };
+
+  f32x16 acc[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) gload(kt + 1);
+    // lane l feeds A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31] of each 32x32x2 product
+    const float *as = &As[buf][(w * 32 + (l & 31)) * LD + (l >> 5)];
+    const float *bs = &Bs[buf][(l & 31) * LD + (l >> 5)];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a = as[kk];
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[nt * 32 * LD + kk], acc[nt], 0, 0, 0);
+    }
+    if (kt + 1 < KT) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // C/D map of the 32x32 tile: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+#pragma unroll
+  for (int nt = 0; nt < 5; ++nt) {
+    const int n = n0 + nt * 32 + (l & 31);
+    const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      if (m < g.M) g.C[(size_t)m * g.ldc + n] = acc[nt][r] + bv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row kernels: one wavefront per agent, lane l owns elements l, l+64, l+128 (< 160) of a 160-vector.
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+struct Row3 {
+  float v[3];
+};
+__device__ inline Row3 row_load(const float *p, int l) {
+  Row3 r;
+  r.v[0] = p[l], r.v[1] = p[l + 64], r.v[2] = (l < HID - 128) ? p[l + 128] : 0.f;
+  return r;
+}
+__device__ inline void row_store(float *p, int l, const Row3 &r) {
+  p[l] = r.v[0], p[l + 64] = r.v[1];
+  if (l < HID - 128) p[l + 128] = r.v[2];
+}
+// x * 160 / (sum|x| + 1e-8)   Modules.hpp:43,46,108,112,126,130
+__device__ inline Row3 row_norm(const Row3 &x) {
+  const float s = wave_sum(fabsf(x.v[0]) + fabsf(x.v[1]) + fabsf(x.v[2])) + 1e-8f;
+  Row3 y;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) y.v[i] = x.v[i] * (float)HID / s;
+  return y;
+}
+__device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// torch GRU cell, gate order r,z,n; gi = W_ih x + b_ih, gh = W_hh h + b_hh (both from k_gemm):
+//   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
+__device__ inline Row3 gru_cell(const float *gi, const float *gh, const Row3 &h, int l) {
+  Row3 o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = l + 64 * i;
+    if (e < HID) {
+      const float r = sigmoidf_(gi[e] + gh[e]);
+      const float z = sigmoidf_(gi[HID + e] + gh[HID + e]);
+      const float n = tanhf(gi[2 * HID + e] + r * gh[2 * HID + e]);
+      o.v[i] = (1.f - z) * n + z * h.v[i];
+    } else {
+      o.v[i] = 0.f;
+    }
+  }
+  return o;
+}
+
+#define SFP_ROW_PROLOGUE            \
+  const int l = threadIdx.x & 63;   \
+  const int a = blockIdx.x * 4 + (threadIdx.x >> 6); \
+  if (a >= agents) return;
+
+__global__ __launch_bounds__(256) void k_norm(const float *x, float *y, int agents) {
+  SFP_ROW_PROLOGUE
+  row_store(y + (size_t)a * HID, l, row_norm(row_load(x + (size_t)a * HID, l)));
+}
+
+// gru0 + the assembly of `combined` (Modules.hpp:110-123): comb[0:160] = norm(h0') + feat_n,
+// comb[160:329] = norm(pov), comb[329:336] = 0 (K padding)
+__global__ __launch_bounds__(256) void k_gru0(const float *gi, const float *gh, float *h, const float *feat_n,
+                                              const float *obs, const float *action_input, float *comb, int agents) {
+  SFP_ROW_PROLOGUE
+  float *hp = h + (size_t)a * HID;
+  const Row3 hn = gru_cell(gi + (size_t)a * G3, gh + (size_t)a * G3, row_load(hp, l), l);
+  row_store(hp, l, hn);
+  const Row3 on = row_norm(hn), f = row_load(feat_n + (size_t)a * HID, l);
+  Row3 c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c.v[i] = on.v[i] + f.v[i];
+  float *cp = comb + (size_t)a * COMB_PAD;
+  row_store(cp, l, c);
+  // pov: cells (-1,0) (0,-1) (0,0) (0,1) (1,0) around the centre, 32 channels each, then the action one-hot
+  const float *op = obs + (size_t)a * OBS_F;
+  float pv[3];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = l + 64 * i;
+    float v = 0.f;
+    if (e < 5 * OBS_C) {
+      const int cell = e >> 5, ch = e & 31;
+      const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0;
+      const int dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
+      v = op[(size_t)ch * OBS_W * OBS_W + (OBS_W / 2 + dy) * OBS_W + (OBS_W / 2 + dx)];
+    } else if (e < POV) {
+      v = action_input[(size_t)a * ACT + (e - 5 * OBS_C)];
+    }
+    pv[i] = v;
+    s += fabsf(v);
+  }
+  s = wave_sum(s) + 1e-8f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = l + 64 * i;
+    if (e < COMB_PAD - HID) cp[HID + e] = (e < POV) ? pv[i] * (float)HID / s : 0.f;
+  }
+}
+
+// gru1 + residual (Modules.hpp:128-131): out = norm(h1') + gated_n
+__global__ __launch_bounds__(256) void k_gru1(const float *gi, const float *gh, float *h, const float *gated_n,
+                                              float *out, int agents) {
+  SFP_ROW_PROLOGUE
+  float *hp = h + (size_t)a * HID;
+  const Row3 hn = gru_cell(gi + (size_t)a * G3, gh + (size_t)a * G3, row_load(hp, l), l);
+  row_store(hp, l, hn);
+  const Row3 on = row_norm(hn), gn = row_load(gated_n + (size_t)a * HID, l);
+  Row3 o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o.v[i] = on.v[i] + gn.v[i];
+  row_store(out + (size_t)a * HID, l, o);
+}
+
+// one ResB layer after its Linear (Modules.hpp:45-46): x <- norm(relu(lin) + x)
+__global__ __launch_bounds__(256) void k_res(const float *lin, float *x, int agents) {
+  SFP_ROW_PROLOGUE
+  float *xp = x + (size_t)a * HID;
+  const Row3 y = row_load(lin + (size_t)a * HID, l), xv = row_load(xp, l);
+  Row3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r.v[i] = fmaxf(y.v[i], 0.f) + xv.v[i];
+  row_store(xp, l, row_norm(r));
+}
+
+// the two output layers (Modules.hpp:172-175): p = softmax(W_p x_p + b_p) + 1e-8, v = sigmoid(W_v x_v + b_v)
+__global__ __launch_bounds__(256) void k_heads(const float *xp, const float *xv, const float *wp, const float *bp,
+                                               const float *wv, const float *bv, float *probs, float *value,
+                                               int agents) {
+  SFP_ROW_PROLOGUE
+  const Row3 p = row_load(xp + (size_t)a * HID, l), v = row_load(xv + (size_t)a * HID, l);
+  float logit[ACT];
+#pragma unroll
+  for (int k = 0; k < ACT; ++k) {
+    const Row3 wr = row_load(wp + k * HID, l);
+    logit[k] = wave_sum(p.v[0] * wr.v[0] + p.v[1] * wr.v[1] + p.v[2] * wr.v[2]) + bp[k];
+  }
+  const Row3 wr = row_load(wv, l);
+  const float val = wave_sum(v.v[0] * wr.v[0] + v.v[1] * wr.v[1] + v.v[2] * wr.v[2]) + bv[0];
+  float mx = logit[0];
+#pragma unroll
+  for (int k = 1; k < ACT; ++k) mx = fmaxf(mx, logit[k]);
+  float e[ACT], s = 0.f;
+#pragma unroll
+  for (int k = 0; k < ACT; ++k) e[k] = expf(logit[k] - mx), s += e[k];
+  if (l < ACT) {
+    float mine = e[0];
+#pragma unroll
+    for (int k = 1; k < ACT; ++k) mine = (l == k) ? e[k] : mine;
+    probs[(size_t)a * ACT + l] = mine / s + 1e-8f;
+  }
+  if (l == 0) value[a] = sigmoidf_(val);
+}
+
+__global__ void k_reset_memory(float *h0, float *h1, float *action_input, const uint8_t *mask, int agents) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = i / HID, e = i - a * HID;
+  if (a >= agents || (mask && !mask[a])) return;
+  h0[i] = 0.f, h1[i] = 0.f;
+  if (e < ACT) action_input[(size_t)a * ACT + e] = (e == 0) ? 1.f : 0.f;
+}
+
+__device__ inline uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct ActStr {
+  char c[ACT];
+};
+
+// Agent::predict tail + Agent::update (Agent.hpp:200-222)
+__global__ void k_act(const float *probs, float *action_input, ActStr as, uint64_t seed, uint64_t draw, int greedy,
+                      uint8_t *cmd, int32_t *action, int agents) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= agents) return;
+  float v[ACT];
+#pragma unroll
+  for (int k = 0; k < ACT; ++k) v[k] = probs[(size_t)a * ACT + k];
+  const float sc = 0.5f / (1.f - v[0] + 1e-5f);
+#pragma unroll
+  for (int k = 1; k < ACT; ++k) v[k] *= sc;
+  v[0] = 0.5f;
+  int pick = 0;
+  if (greedy) {
+#pragma unroll
+    for (int k = 1; k < ACT; ++k)
+      if (v[k] > v[pick]) pick = k;
+  } else {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < ACT; ++k) tot += v[k];
+    const uint64_t r = mix64(mix64(seed ^ mix64((uint64_t)a)) + draw);
+    const float u = (float)(r >> 40) * (1.0f / 16777216.0f) * tot;  // [0, tot)
+    float c = 0.f;
+    bool found = false;
+    pick = ACT - 1;
+#pragma unroll
+    for (int k = 0; k < ACT - 1; ++k) {
+      c += v[k];
+      if (!found && u < c) pick = k, found = true;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ACT; ++k) action_input[(size_t)a * ACT + k] = (k == pick) ? 1.f : 0.f;
+  cmd[a] = (uint8_t)as.c[pick];
+  if (action) action[a] = pick;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------------------
+#define SFP_HIP(call)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) return sf::fail(SF_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct Policy {
+  int device = 0, max_agents = 0;
+  hipStream_t stream = nullptr;
+  uint64_t draws = 0;
+  // parameters
+  float *conv_w[4] = {}, *gru_w_ih[2] = {}, *gru_w_hh[2] = {}, *gru_b_ih[2] = {}, *gru_b_hh[2] = {};
+  float *comb_w = nullptr, *comb_b = nullptr;
+  float *res_w[2][3] = {}, *res_b[2][3] = {}, *head_w[2] = {}, *head_b[2] = {};  // [0] policy, [1] value
+  // per-agent state and scratch
+  float *h[2] = {}, *action_input = nullptr;
+  float *act[3] = {};  // NHWC conv outputs 15x15, 7x7, 3x3
+  float *feat = nullptr, *feat_n = nullptr, *gi = nullptr, *gh = nullptr, *comb = nullptr, *gated = nullptr,
+        *gated_n = nullptr, *out = nullptr, *x[2] = {}, *lin = nullptr;
+  std::vector<void *> owned;
+  // timing of the GEMM launches
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t used_events = 0;
+  double flop = 0;
+
+  ~Policy() {
+    for (void *p : owned) (void)hipFree(p);
+    for (auto &ev : events) (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
+  }
+  int dalloc(float **p, size_t floats) {
+    void *d = nullptr;
+    if (hipMalloc(&d, floats * sizeof(float)) != hipSuccess) return fail(SF_ERR_MEMORY, "hipMalloc failed (policy)");
+    owned.push_back(d);
+    *p = (float *)d;
+    return SF_OK;
+  }
+  int upload(float **p, const float *src, size_t floats) {
+    if (!src) return fail(SF_ERR_ARG, "sf_policy_weights has a null pointer");
+    int rc = dalloc(p, floats);
+    if (rc) return rc;
+    SFP_HIP(hipMemcpy(*p, src, floats * sizeof(float), hipMemcpyHostToDevice));
+    return SF_OK;
+  }
+
+  template <int WAVES, int MODE>
+  void launch_t(const Gemm &g) {
+    dim3 grid((unsigned)((g.M + WAVES * 32 - 1) / (WAVES * 32)), (unsigned)(g.N / BN));
+    hipLaunchKernelGGL((k_gemm<WAVES, MODE>), grid, dim3(WAVES * 64), 0, stream, g);
+  }
+  template <int MODE>
+  void launch_m(const Gemm &g) {
+    if (g.M >= 65536) launch_t<4, MODE>(g);
+    else if (g.M >= 16384) launch_t<2, MODE>(g);
+    else launch_t<1, MODE>(g);
+  }
+  int gemm(const Gemm &g, int mode) {
+    if (g.K % BK || g.N % BN || g.M < 1) return fail(SF_ERR_ARG, "policy gemm: unsupported shape");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) {
+      if (used_events == events.size()) {
+        hipEvent_t a, b;
+        SFP_HIP(hipEventCreate(&a));
+        SFP_HIP(hipEventCreate(&b));
+        events.emplace_back(a, b);
+      }
+      e0 = events[used_events].first, e1 = events[used_events].second;
+      ++used_events;
+      flop += 2.0 * g.M * g.N * g.K;
+      SFP_HIP(hipEventRecord(e0, stream));
+    }
+    switch (mode) {
+      case MODE_DENSE: launch_m<MODE_DENSE>(g); break;
+      case MODE_NHWC: launch_m<MODE_NHWC>(g); break;
+      default: launch_m<MODE_NCHW>(g); break;
+    }
+    SFP_HIP(hipGetLastError());
+    if (timing) SFP_HIP(hipEventRecord(e1, stream));
+    return SF_OK;
+  }
+  int dense(const float *A, int lda, const float *W, const float *bias, float *C, int ldc, int M, int N, int K) {
+    Gemm g{A, W, bias, C, M, N, K, lda, ldc, 0, 0, 0};
+    return gemm(g, MODE_DENSE);
+  }
+  int conv(const float *in, const float *W, float *outp, int agents, int S, int Cin, int nchw) {
+    const int So = (S - 3) / 2 + 1;
+    Gemm g{in, W, nullptr, outp, agents * So * So, HID, Cin * 9, 0, HID, S, Cin, So};
+    return gemm(g, nchw ? MODE_NCHW : MODE_NHWC);
+  }
+};
+
+static int check_agents(Policy *p, int agents) {
+  if (!p) return fail(SF_ERR_ARG, "null policy");
+  if (agents < 1 || agents > p->max_agents) return fail(SF_ERR_ARG, "agents out of range for this policy");
+  return SF_OK;
+}
+
+static int create(const sf_policy_weights *w, int max_agents, int device, sf_policy **out) {
+  if (!w || !out) return fail(SF_ERR_ARG, "null argument");
+  if (w->abi_version != SF_POLICY_ABI_VERSION) return fail(SF_ERR_ARG, "sf_policy_weights.abi_version mismatch");
+  if (max_agents < 1 || max_agents > (1 << 20)) return fail(SF_ERR_ARG, "max_agents must be 1..1048576");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+    return fail(SF_ERR_DEVICE, "no HIP device: the policy network has no CPU path");
+  if (device < 0 || device >= n) return fail(SF_ERR_DEVICE, "device ordinal out of range");
+  SFP_HIP(hipSetDevice(device));
+  Policy *p = new Policy();
+  p->device = device, p->max_agents = max_agents;
+  int rc = SF_OK;
+#define SFP_TRY(x)   \
+  if ((rc = (x))) {  \
+    delete p;        \
+    return rc;       \
+  }
+  for (int i = 0; i < 4; ++i)
+    if (!w->conv_w[i]) SFP_TRY(fail(SF_ERR_ARG, "conv weight is null"));
+  SFP_TRY(p->upload(&p->conv_w[0], w->conv_w[0], (size_t)HID * OBS_C * 9));
+  for (int i = 1; i < 4; ++i) {
+    // [n][cin][ky][kx] -> [n][ky][kx][cin]: the K-order of an NHWC im2col row
+    std::vector<float> perm((size_t)HID * HID * 9);
+    for (int nn = 0; nn < HID; ++nn)
+      for (int c = 0; c < HID; ++c)
+        for (int tap = 0; tap < 9; ++tap)
+          perm[((size_t)nn * 9 + tap) * HID + c] = w->conv_w[i][((size_t)nn * HID + c) * 9 + tap];
+    SFP_TRY(p->upload(&p->conv_w[i], perm.data(), perm.size()));
+  }
+  for (int g = 0; g < 2; ++g) {
+    SFP_TRY(p->upload(&p->gru_w_ih[g], w->gru_w_ih[g], (size_t)G3 * HID));
+    SFP_TRY(p->upload(&p->gru_w_hh[g], w->gru_w_hh[g], (size_t)G3 * HID));
+    SFP_TRY(p->upload(&p->gru_b_ih[g], w->gru_b_ih[g], G3));
+    SFP_TRY(p->upload(&p->gru_b_hh[g], w->gru_b_hh[g], G3));
+  }
+  {
+    if (!w->comb_w) SFP_TRY(fail(SF_ERR_ARG, "combined_processor weight is null"));
+    std::vector<float> pad((size_t)HID * COMB_PAD, 0.f);
+    for (int nn = 0; nn < HID; ++nn) std::memcpy(&pad[(size_t)nn * COMB_PAD], w->comb_w + (size_t)nn * COMB, COMB * sizeof(float));
+    SFP_TRY(p->upload(&p->comb_w, pad.data(), pad.size()));
+    SFP_TRY(p->upload(&p->comb_b, w->comb_b, HID));
+  }
+  for (int i = 0; i < 3; ++i) {
+    SFP_TRY(p->upload(&p->res_w[0][i], w->policy_res_w[i], (size_t)HID * HID));
+    SFP_TRY(p->upload(&p->res_b[0][i], w->policy_res_b[i], HID));
+    SFP_TRY(p->upload(&p->res_w[1][i], w->value_res_w[i], (size_t)HID * HID));
+    SFP_TRY(p->upload(&p->res_b[1][i], w->value_res_b[i], HID));
+  }
+  SFP_TRY(p->upload(&p->head_w[0], w->policy_w, (size_t)ACT * HID));
+  SFP_TRY(p->upload(&p->head_b[0], w->policy_b, ACT));
+  SFP_TRY(p->upload(&p->head_w[1], w->value_w, HID));
+  SFP_TRY(p->upload(&p->head_b[1], w->value_b, 1));
+  const size_t B = (size_t)max_agents;
+  SFP_TRY(p->dalloc(&p->h[0], B * HID));
+  SFP_TRY(p->dalloc(&p->h[1], B * HID));
+  SFP_TRY(p->dalloc(&p->action_input, B * ACT));
+  SFP_TRY(p->dalloc(&p->act[0], B * 225 * HID));
+  SFP_TRY(p->dalloc(&p->act[1], B * 49 * HID));
+  SFP_TRY(p->dalloc(&p->act[2], B * 9 * HID));
+  SFP_TRY(p->dalloc(&p->feat, B * HID));
+  SFP_TRY(p->dalloc(&p->feat_n, B * HID));
+  SFP_TRY(p->dalloc(&p->gi, B * G3));
+  SFP_TRY(p->dalloc(&p->gh, B * G3));
+  SFP_TRY(p->dalloc(&p->comb, B * COMB_PAD));
+  SFP_TRY(p->dalloc(&p->gated, B * HID));
+  SFP_TRY(p->dalloc(&p->gated_n, B * HID));
+  SFP_TRY(p->dalloc(&p->out, B * HID));
+  SFP_TRY(p->dalloc(&p->x[0], B * HID));
+  SFP_TRY(p->dalloc(&p->x[1], B * HID));
+  SFP_TRY(p->dalloc(&p->lin, B * HID));
+#undef SFP_TRY
+  *out = reinterpret_cast<sf_policy *>(p);
+  return sf_policy_reset_memory(*out, nullptr);
+}
+
+static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, float *d_value) {
+  int rc = check_agents(p, agents);
+  if (rc) return rc;
+  if (!d_obs || !d_probs || !d_value) return fail(SF_ERR_ARG, "null buffer");
+  SFP_HIP(hipSetDevice(p->device));
+  const dim3 rg((unsigned)((agents + 3) / 4)), rb(256);
+  hipStream_t st = p->stream;
+  // GameCNN                                                                    Modules.hpp:66-71
+  if ((rc = p->conv(d_obs, p->conv_w[0], p->act[0], agents, 31, OBS_C, 1))) return rc;
+  if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, HID, 0))) return rc;
+  if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, HID, 0))) return rc;
+  if ((rc = p->conv(p->act[2], p->conv_w[3], p->feat, agents, 3, HID, 0))) return rc;
+  hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->feat, p->feat_n, agents);                     // :108
+  // gru0                                                                                       :110-113
+  if ((rc = p->dense(p->feat_n, HID, p->gru_w_ih[0], p->gru_b_ih[0], p->gi, G3, agents, G3, HID))) return rc;
+  if ((rc = p->dense(p->h[0], HID, p->gru_w_hh[0], p->gru_b_hh[0], p->gh, G3, agents, G3, HID))) return rc;
+  hipLaunchKernelGGL(k_gru0, rg, rb, 0, st, p->gi, p->gh, p->h[0], p->feat_n, d_obs, p->action_input, p->comb, agents);
+  // combined_processor                                                                         :125-126
+  if ((rc = p->dense(p->comb, COMB_PAD, p->comb_w, p->comb_b, p->gated, HID, agents, HID, COMB_PAD))) return rc;
+  hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->gated, p->gated_n, agents);
+  // gru1                                                                                       :128-131
+  if ((rc = p->dense(p->gated_n, HID, p->gru_w_ih[1], p->gru_b_ih[1], p->gi, G3, agents, G3, HID))) return rc;
+  if ((rc = p->dense(p->h[1], HID, p->gru_w_hh[1], p->gru_b_hh[1], p->gh, G3, agents, G3, HID))) return rc;
+  hipLaunchKernelGGL(k_gru1, rg, rb, 0, st, p->gi, p->gh, p->h[1], p->gated_n, p->out, agents);
+  // heads: ResB then Linear                                                                    :41-48,172-175
+  for (int hd = 0; hd < 2; ++hd) {
+    hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->out, p->x[hd], agents);
+    for (int i = 0; i < 3; ++i) {
+      if ((rc = p->dense(p->x[hd], HID, p->res_w[hd][i], p->res_b[hd][i], p->lin, HID, agents, HID, HID))) return rc;
+      hipLaunchKernelGGL(k_res, rg, rb, 0, st, p->lin, p->x[hd], agents);
+    }
+  }
+  hipLaunchKernelGGL(k_heads, rg, rb, 0, st, p->x[0], p->x[1], p->head_w[0], p->head_b[0], p->head_w[1], p->head_b[1],
+                     d_probs, d_value, agents);
+  SFP_HIP(hipGetLastError());
+  return SF_OK;
+}
+
+}  // namespace sfp
+
+using sfp::Policy;
+
+extern "C" {
+
+int sf_policy_abi_version(void) { return SF_POLICY_ABI_VERSION; }
+
+int sf_policy_create(const sf_policy_weights *w, int32_t max_agents, int32_t device, sf_policy **out) {
+  return sfp::create(w, max_agents, device, out);
+}
+
+void sf_policy_destroy(sf_policy *p) { delete reinterpret_cast<Policy *>(p); }
+
+int sf_policy_reset_memory(sf_policy *pp, const uint8_t *d_mask) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
+  SFP_HIP(hipSetDevice(p->device));
+  const int n = p->max_agents * sfp::HID;
+  hipLaunchKernelGGL(sfp::k_reset_memory, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->h[0], p->h[1],
+                     p->action_input, d_mask, p->max_agents);
+  SFP_HIP(hipGetLastError());
+  return SF_OK;
+}
+
+int sf_policy_forward(sf_policy *pp, const float *d_obs, int32_t agents, float *d_probs, float *d_value) {
+  return sfp::forward(reinterpret_cast<Policy *>(pp), d_obs, agents, d_probs, d_value);
+}
+
+int sf_policy_act(sf_policy *pp, const float *d_probs, int32_t agents, const char *action_string, uint64_t seed,
+                  int32_t greedy, uint8_t *d_cmd, int32_t *d_action) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  int rc = sfp::check_agents(p, agents);
+  if (rc) return rc;
+  if (!d_probs || !d_cmd || !action_string) return sfp::fail(SF_ERR_ARG, "null buffer");
+  if (std::strlen(action_string) != (size_t)sfp::ACT) return sfp::fail(SF_ERR_ARG, "action_string must have 9 chars");
+  sfp::ActStr as;
+  std::memcpy(as.c, action_string, sfp::ACT);
+  SFP_HIP(hipSetDevice(p->device));
+  hipLaunchKernelGGL(sfp::k_act, dim3((unsigned)((agents + 255) / 256)), dim3(256), 0, p->stream, d_probs,
+                     p->action_input, as, seed, p->draws++, greedy, d_cmd, d_action, agents);
+  SFP_HIP(hipGetLastError());
+  return SF_OK;
+}
+
+int sf_policy_get_memory(sf_policy *pp, int32_t agent, float *h, float *action_input) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p || agent < 0 || agent >= p->max_agents || !h || !action_input) return sfp::fail(SF_ERR_ARG, "bad argument");
+  SFP_HIP(hipSetDevice(p->device));
+  SFP_HIP(hipStreamSynchronize(p->stream));
+  for (int g = 0; g < 2; ++g)
+    SFP_HIP(hipMemcpy(h + g * sfp::HID, p->h[g] + (size_t)agent * sfp::HID, sfp::HID * sizeof(float), hipMemcpyDeviceToHost));
+  SFP_HIP(hipMemcpy(action_input, p->action_input + (size_t)agent * sfp::ACT, sfp::ACT * sizeof(float), hipMemcpyDeviceToHost));
+  return SF_OK;
+}
+
+int sf_policy_set_memory(sf_policy *pp, int32_t agent, const float *h, const float *action_input) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p || agent < 0 || agent >= p->max_agents || !h || !action_input) return sfp::fail(SF_ERR_ARG, "bad argument");
+  SFP_HIP(hipSetDevice(p->device));
+  SFP_HIP(hipStreamSynchronize(p->stream));
+  for (int g = 0; g < 2; ++g)
+    SFP_HIP(hipMemcpy(p->h[g] + (size_t)agent * sfp::HID, h + g * sfp::HID, sfp::HID * sizeof(float), hipMemcpyHostToDevice));
+  SFP_HIP(hipMemcpy(p->action_input + (size_t)agent * sfp::ACT, action_input, sfp::ACT * sizeof(float), hipMemcpyHostToDevice));
+  return SF_OK;
+}
+
+int sf_policy_set_stream(sf_policy *pp, void *hip_stream) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
+  p->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return SF_OK;
+}
+
+int sf_policy_synchronize(sf_policy *pp) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
+  SFP_HIP(hipSetDevice(p->device));
+  SFP_HIP(hipStreamSynchronize(p->stream));
+  return SF_OK;
+}
+
+int sf_policy_kernel_time(sf_policy *pp, int32_t enable, float *ms, double *flop, int32_t *launches) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
+  SFP_HIP(hipSetDevice(p->device));
+  SFP_HIP(hipStreamSynchronize(p->stream));
+  float total = 0.f;
+  for (size_t i = 0; i < p->used_events; ++i) {
+    float t = 0.f;
+    SFP_HIP(hipEventElapsedTime(&t, p->events[i].first, p->events[i].second));
+    total += t;
+  }
+  if (ms) *ms = total;
+  if (flop) *flop = p->flop;
+  if (launches) *launches = (int32_t)p->used_events;
+  p->used_events = 0;
+  p->flop = 0;
+  p->timing = enable != 0;
+  return SF_OK;
+}
+
+}  // extern "C"

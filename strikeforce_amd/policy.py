@@ -1,0 +1,190 @@
+"""ctypes plumbing for the on-device policy network (include/strikeforce_policy.h).
+
+``PolicyBatch`` evaluates the reference's bot network (bots/bot-0.5/Modules.hpp:54-179) for every agent of an
+arena batch on the GPU, straight from the observation buffer ``ArenaBatch.observe_device`` wrote.  Parameters are
+passed as a dict of float32 numpy arrays keyed by the reference's parameter names (``named_parameters()`` of
+``AgentModel``); ``init_parameters`` makes a random set with torch's default initialisers for the same shapes.
+There is no CPU path: without the HIP library / a GPU this raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import env
+
+HIDDEN, ACTIONS, CONVS, RES_LAYERS = 160, 9, 4, 3
+OBS_CHANNELS, OBS_WINDOW = 32, 31
+ACTION_STRING = "+xzqeawsd"  # gameplay::prepare, bots/bot-0.5/Custom.hpp:162
+POLICY_ABI_VERSION = 1
+
+_FP = C.POINTER(C.c_float)
+
+
+class Weights(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("conv_w", _FP * CONVS),
+        ("gru_w_ih", _FP * 2), ("gru_w_hh", _FP * 2), ("gru_b_ih", _FP * 2), ("gru_b_hh", _FP * 2),
+        ("comb_w", _FP), ("comb_b", _FP),
+        ("value_res_w", _FP * RES_LAYERS), ("value_res_b", _FP * RES_LAYERS), ("value_w", _FP), ("value_b", _FP),
+        ("policy_res_w", _FP * RES_LAYERS), ("policy_res_b", _FP * RES_LAYERS), ("policy_w", _FP), ("policy_b", _FP),
+    ]
+
+
+def parameter_shapes():
+    """name -> shape, the names and shapes of AgentModel's parameters (Modules.hpp:37,62,87-91,147-152)."""
+    s = {}
+    for i in range(CONVS):
+        s["backbone.cnn.conv%d.weight" % i] = (HIDDEN, OBS_CHANNELS if i == 0 else HIDDEN, 3, 3)
+    for g in range(2):
+        s["backbone.gru%d.weight_ih_l0" % g] = (3 * HIDDEN, HIDDEN)
+        s["backbone.gru%d.weight_hh_l0" % g] = (3 * HIDDEN, HIDDEN)
+        s["backbone.gru%d.bias_ih_l0" % g] = (3 * HIDDEN,)
+        s["backbone.gru%d.bias_hh_l0" % g] = (3 * HIDDEN,)
+    s["backbone.combined_processor.0.weight"] = (HIDDEN, 2 * HIDDEN + ACTIONS)
+    s["backbone.combined_processor.0.bias"] = (HIDDEN,)
+    for head, n_out in (("value", 1), ("policy", ACTIONS)):
+        for i in range(RES_LAYERS):
+            s["%s.0.lin%d.weight" % (head, i)] = (HIDDEN, HIDDEN)
+            s["%s.0.lin%d.bias" % (head, i)] = (HIDDEN,)
+        s["%s.1.weight" % head] = (n_out, HIDDEN)
+        s["%s.1.bias" % head] = (n_out,)
+    return s
+
+
+def init_parameters(seed=0, gain=1.0):
+    """Random parameters of the reference's shapes: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like torch's defaults for
+    Conv2d / Linear, U(-1/sqrt(hidden), 1/sqrt(hidden)) for GRU.  (There is no network to fetch checkpoints.)"""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shape in parameter_shapes().items():
+        if ".gru" in name:
+            bound = 1.0 / np.sqrt(HIDDEN)
+        elif name.endswith(".bias"):
+            w = parameter_shapes()[name[:-5] + ".weight"]
+            bound = 1.0 / np.sqrt(np.prod(w[1:]))
+        else:
+            bound = 1.0 / np.sqrt(np.prod(shape[1:]))
+        out[name] = (rng.uniform(-bound, bound, size=shape) * gain).astype(np.float32)
+    return out
+
+
+def _bind(L):
+    if getattr(L, "_sf_policy_bound", False):
+        return
+    vp = C.c_void_p
+    L.sf_policy_create.argtypes = [C.POINTER(Weights), C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.sf_policy_destroy.argtypes = [vp]
+    L.sf_policy_destroy.restype = None
+    L.sf_policy_reset_memory.argtypes = [vp, vp]
+    L.sf_policy_forward.argtypes = [vp, vp, C.c_int32, vp, vp]
+    L.sf_policy_act.argtypes = [vp, vp, C.c_int32, C.c_char_p, C.c_uint64, C.c_int32, vp, vp]
+    L.sf_policy_get_memory.argtypes = [vp, C.c_int32, _FP, _FP]
+    L.sf_policy_set_memory.argtypes = [vp, C.c_int32, _FP, _FP]
+    L.sf_policy_set_stream.argtypes = [vp, vp]
+    L.sf_policy_synchronize.argtypes = [vp]
+    L.sf_policy_kernel_time.argtypes = [vp, C.c_int32, _FP, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    for n in EXPORTS:
+        if n != "sf_policy_destroy":
+            getattr(L, n).restype = C.c_int
+    L._sf_policy_bound = True
+
+
+# every symbol include/strikeforce_policy.h declares
+EXPORTS = ["sf_policy_create", "sf_policy_destroy", "sf_policy_reset_memory", "sf_policy_forward", "sf_policy_act",
+           "sf_policy_get_memory", "sf_policy_set_memory", "sf_policy_set_stream", "sf_policy_synchronize",
+           "sf_policy_kernel_time", "sf_policy_abi_version"]
+
+
+class PolicyBatch:
+    """`max_agents` independent copies of the reference's AgentModel state over one shared parameter set."""
+
+    def __init__(self, params, max_agents, device=0):
+        self.L = env.load_library()
+        _bind(self.L)
+        self.max_agents = int(max_agents)
+        shapes = parameter_shapes()
+        keep = {}
+        for name, shape in shapes.items():
+            if name not in params:
+                raise ValueError("missing parameter %s" % name)
+            a = np.ascontiguousarray(params[name], dtype=np.float32)
+            if a.shape != tuple(shape):
+                raise ValueError("parameter %s has shape %s, expected %s" % (name, a.shape, shape))
+            keep[name] = a
+        ptr = lambda n: keep[n].ctypes.data_as(_FP)
+        w = Weights()
+        w.abi_version = POLICY_ABI_VERSION
+        for i in range(CONVS):
+            w.conv_w[i] = ptr("backbone.cnn.conv%d.weight" % i)
+        for g in range(2):
+            w.gru_w_ih[g] = ptr("backbone.gru%d.weight_ih_l0" % g)
+            w.gru_w_hh[g] = ptr("backbone.gru%d.weight_hh_l0" % g)
+            w.gru_b_ih[g] = ptr("backbone.gru%d.bias_ih_l0" % g)
+            w.gru_b_hh[g] = ptr("backbone.gru%d.bias_hh_l0" % g)
+        w.comb_w, w.comb_b = ptr("backbone.combined_processor.0.weight"), ptr("backbone.combined_processor.0.bias")
+        for i in range(RES_LAYERS):
+            w.value_res_w[i], w.value_res_b[i] = ptr("value.0.lin%d.weight" % i), ptr("value.0.lin%d.bias" % i)
+            w.policy_res_w[i], w.policy_res_b[i] = ptr("policy.0.lin%d.weight" % i), ptr("policy.0.lin%d.bias" % i)
+        w.value_w, w.value_b = ptr("value.1.weight"), ptr("value.1.bias")
+        w.policy_w, w.policy_b = ptr("policy.1.weight"), ptr("policy.1.bias")
+        self.h = C.c_void_p()
+        rc = self.L.sf_policy_create(C.byref(w), self.max_agents, int(device), C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise env.StrikeForceError("sf_policy_create failed (%d): %s" % (rc, self.L.sf_last_error().decode()))
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise env.StrikeForceError("%s failed (%d): %s" % (what, rc, self.L.sf_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sf_policy_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        self._ck(self.L.sf_policy_set_stream(self.h, C.c_void_p(hip_stream)), "sf_policy_set_stream")
+
+    def synchronize(self):
+        self._ck(self.L.sf_policy_synchronize(self.h), "sf_policy_synchronize")
+
+    def reset_memory(self, d_mask_ptr=None):
+        self._ck(self.L.sf_policy_reset_memory(self.h, C.c_void_p(d_mask_ptr) if d_mask_ptr else None),
+                 "sf_policy_reset_memory")
+
+    def forward(self, d_obs_ptr, agents, d_probs_ptr, d_value_ptr):
+        self._ck(self.L.sf_policy_forward(self.h, C.c_void_p(d_obs_ptr), int(agents), C.c_void_p(d_probs_ptr),
+                                          C.c_void_p(d_value_ptr)), "sf_policy_forward")
+
+    def act(self, d_probs_ptr, agents, d_cmd_ptr, seed=0, greedy=False, d_action_ptr=None,
+            action_string=ACTION_STRING):
+        self._ck(self.L.sf_policy_act(self.h, C.c_void_p(d_probs_ptr), int(agents), action_string.encode(),
+                                      C.c_uint64(seed), 1 if greedy else 0, C.c_void_p(d_cmd_ptr),
+                                      C.c_void_p(d_action_ptr) if d_action_ptr else None), "sf_policy_act")
+
+    def get_memory(self, agent):
+        h = np.zeros((2, HIDDEN), dtype=np.float32)
+        a = np.zeros(ACTIONS, dtype=np.float32)
+        self._ck(self.L.sf_policy_get_memory(self.h, int(agent), h.ctypes.data_as(_FP), a.ctypes.data_as(_FP)),
+                 "sf_policy_get_memory")
+        return h, a
+
+    def set_memory(self, agent, h, action_input):
+        h = np.ascontiguousarray(h, dtype=np.float32).reshape(2, HIDDEN)
+        a = np.ascontiguousarray(action_input, dtype=np.float32).reshape(ACTIONS)
+        self._ck(self.L.sf_policy_set_memory(self.h, int(agent), h.ctypes.data_as(_FP), a.ctypes.data_as(_FP)),
+                 "sf_policy_set_memory")
+
+    def kernel_time(self, enable=True):
+        """(ms, flop, launches) of the MFMA GEMM launches since the last call; arms / disarms the timers."""
+        ms, fl, n = C.c_float(), C.c_double(), C.c_int32()
+        self._ck(self.L.sf_policy_kernel_time(self.h, 1 if enable else 0, C.byref(ms), C.byref(fl), C.byref(n)),
+                 "sf_policy_kernel_time")
+        return ms.value, fl.value, n.value

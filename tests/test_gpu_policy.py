@@ -1,0 +1,185 @@
+"""The on-device policy network (include/strikeforce_policy.h, f32 MFMA kernels) against the PyTorch f32 restatement
+of the reference's model (oracle/policy_ref.py).  Floating point: the kernels differ from torch only in summation
+order, so the gate is a relative tolerance, stated per test."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle_lib import Oracle
+from strikeforce_amd import config, env, policy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import policy_ref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+# |hip - torch| <= ATOL + RTOL * |torch| on probabilities, value and the recurrent state
+RTOL, ATOL = 2e-4, 2e-6
+
+
+def _obs(rng, B):
+    x = rng.uniform(0.0, 2.0, size=(B, 32, 31, 31)).astype(np.float32)
+    x *= rng.uniform(size=x.shape) < 0.3
+    x *= np.where(rng.uniform(size=x.shape) < 0.2, -1.0, 1.0).astype(np.float32)
+    return x
+
+
+def _dev(a):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    torch.cuda.synchronize()
+    return t
+
+
+def _memory(pb, B):
+    h = np.zeros((2, B, 160), dtype=np.float32)
+    a = np.zeros((B, 9), dtype=np.float32)
+    for b in range(B):
+        hb, ab = pb.get_memory(b)
+        h[:, b], a[b] = hb, ab
+    return h, a
+
+
+@pytest.mark.parametrize("B,steps", [(1, 3), (5, 4), (37, 3), (100, 2), (300, 2)])
+def test_forward_matches_reference(B, steps):
+    """B picks the GEMM variant of each layer: 1-wave, 2-wave and 4-wave blocks, ragged last tiles."""
+    rng = np.random.default_rng(B)
+    params = policy.init_parameters(seed=B)
+    pb = policy.PolicyBatch(params, B)
+    h = np.zeros((2, B, 160), dtype=np.float32)
+    a = np.zeros((B, 9), dtype=np.float32)
+    a[:, 0] = 1
+    d_probs = torch.zeros((B, 9), dtype=torch.float32, device="cuda")
+    d_value = torch.zeros(B, dtype=torch.float32, device="cuda")
+    d_cmd = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    d_act = torch.zeros(B, dtype=torch.int32, device="cuda")
+    worst = 0.0
+    for t in range(steps):
+        obs = _obs(rng, B)
+        d_obs = _dev(obs)
+        pb.forward(d_obs.data_ptr(), B, d_probs.data_ptr(), d_value.data_ptr())
+        pb.synchronize()
+        probs, value, h = policy_ref.forward_batched(params, obs, h, a)
+        np.testing.assert_allclose(d_probs.cpu().numpy(), probs, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(d_value.cpu().numpy(), value, rtol=RTOL, atol=ATOL)
+        worst = max(worst, float(np.max(np.abs(d_probs.cpu().numpy() - probs) / probs)))
+        if B <= 37:
+            hg, _ = _memory(pb, B)
+            np.testing.assert_allclose(hg, h, rtol=RTOL, atol=ATOL * 10)
+        # greedy action -> one-hot memory, command chars
+        pb.act(d_probs.data_ptr(), B, d_cmd.data_ptr(), greedy=True, d_action_ptr=d_act.data_ptr())
+        pb.synchronize()
+        acts = d_act.cpu().numpy()
+        v = policy_ref.action_weights(d_probs.cpu().numpy())
+        assert (acts == v.argmax(axis=1)).all()
+        assert bytes(d_cmd.cpu().numpy().tolist()) == "".join(policy.ACTION_STRING[i] for i in acts).encode()
+        a = np.eye(9, dtype=np.float32)[acts]
+        if B <= 37:
+            _, ag = _memory(pb, B)
+            assert (ag == a).all()
+    print("B=%d worst relative error on probabilities %.3g" % (B, worst))
+
+
+def test_reset_memory_mask():
+    B = 6
+    params = policy.init_parameters(seed=3)
+    pb = policy.PolicyBatch(params, B)
+    rng = np.random.default_rng(0)
+    for b in range(B):
+        pb.set_memory(b, rng.normal(size=(2, 160)), np.eye(9)[3])
+    mask = _dev(np.array([1, 0, 0, 1, 0, 1], dtype=np.uint8))
+    pb.reset_memory(mask.data_ptr())
+    pb.synchronize()
+    for b in range(B):
+        h, a = pb.get_memory(b)
+        if b in (0, 3, 5):
+            assert not h.any() and (a == np.eye(9)[0]).all()
+        else:
+            assert h.any() and (a == np.eye(9)[3]).all()
+    pb.reset_memory(None)
+    h, a = pb.get_memory(1)
+    assert not h.any() and a[0] == 1
+
+
+def test_sampling_follows_the_predict_distribution():
+    """Agent.hpp:204-211: weights v (v[0] = 0.5, the rest rescaled) through discrete_distribution."""
+    B = 20000
+    params = policy.init_parameters(seed=1)
+    pb = policy.PolicyBatch(params, B)
+    p = np.array([0.3, 0.05, 0.15, 0.1, 0.05, 0.05, 0.1, 0.1, 0.1], dtype=np.float32)
+    d_probs = _dev(np.tile(p, (B, 1)))
+    d_cmd = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    d_act = torch.zeros(B, dtype=torch.int32, device="cuda")
+    counts = np.zeros(9)
+    for draw in range(5):
+        pb.act(d_probs.data_ptr(), B, d_cmd.data_ptr(), seed=77, d_action_ptr=d_act.data_ptr())
+        pb.synchronize()
+        acts = d_act.cpu().numpy()
+        if draw == 0:
+            first = acts.copy()
+        counts += np.bincount(acts, minlength=9)
+    v = policy_ref.action_weights(p)
+    want = v / v.sum()
+    got = counts / counts.sum()
+    assert np.abs(got - want).max() < 0.006, (got, want)  # ~4 sigma at 100 000 draws
+    # the stream is a pure function of (seed, agent, draw index)
+    pb2 = policy.PolicyBatch(params, B)
+    pb2.act(d_probs.data_ptr(), B, d_cmd.data_ptr(), seed=77, d_action_ptr=d_act.data_ptr())
+    pb2.synchronize()
+    assert (d_act.cpu().numpy() == first).all()
+    pb2.act(d_probs.data_ptr(), B, d_cmd.data_ptr(), seed=78, d_action_ptr=d_act.data_ptr())
+    pb2.synchronize()
+    assert (d_act.cpu().numpy() != first).any()
+
+
+def test_closed_loop_with_the_simulator():
+    """observe_device -> forward -> act -> step_device with nothing leaving the GPU, shadowed on the CPU by the
+    oracle simulator driven with the commands the GPU chose and by the reference network fed the oracle's
+    observations: arena state stays bit-identical and the probabilities stay within tolerance at every step."""
+    arenas, steps = 48, 12
+    w = config.baseline_workload("C2", arenas=arenas)
+    o, g = Oracle(w), env.ArenaBatch(w)
+    tb, sr = w.seeds()
+    o.reset(tb, sr), g.reset(tb, sr)
+    B = arenas * w.cfg.n_agents
+    params = policy.init_parameters(seed=9)
+    pb = policy.PolicyBatch(params, B)
+    d_obs = torch.zeros((B, 32, 31, 31), dtype=torch.float32, device="cuda")
+    d_probs = torch.zeros((B, 9), dtype=torch.float32, device="cuda")
+    d_value = torch.zeros(B, dtype=torch.float32, device="cuda")
+    d_cmd = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    d_act = torch.zeros(B, dtype=torch.int32, device="cuda")
+    h = np.zeros((2, B, 160), dtype=np.float32)
+    a = np.zeros((B, 9), dtype=np.float32)
+    a[:, 0] = 1
+    for t in range(steps):
+        g.observe_device(d_obs.data_ptr())
+        pb.forward(d_obs.data_ptr(), B, d_probs.data_ptr(), d_value.data_ptr())
+        pb.act(d_probs.data_ptr(), B, d_cmd.data_ptr(), seed=5, d_action_ptr=d_act.data_ptr())
+        g.step_device(d_cmd.data_ptr(), 1)
+        g.synchronize()
+        pb.synchronize()
+        probs, value, h = policy_ref.forward_batched(params, o.observe().reshape(B, 32, 31, 31), h, a)
+        np.testing.assert_allclose(d_probs.cpu().numpy(), probs, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(d_value.cpu().numpy(), value, rtol=RTOL, atol=ATOL)
+        acts = d_act.cpu().numpy()
+        a = np.eye(9, dtype=np.float32)[acts]
+        cmd = d_cmd.cpu().numpy()
+        assert bytes(cmd.tolist()) == "".join(policy.ACTION_STRING[i] for i in acts).encode()
+        o.step(cmd)
+        assert (o.digest() == g.digest()).all()
+    assert len(set(acts.tolist())) > 1
+
+
+def test_forward_rejects_bad_arguments():
+    pb = policy.PolicyBatch(policy.init_parameters(0), 4)
+    d = torch.zeros(16, device="cuda")
+    with pytest.raises(env.StrikeForceError, match="out of range"):
+        pb.forward(d.data_ptr(), 5, d.data_ptr(), d.data_ptr())
+    with pytest.raises(env.StrikeForceError, match="null"):
+        pb.forward(0, 4, d.data_ptr(), d.data_ptr())
+    with pytest.raises(env.StrikeForceError, match="9 chars"):
+        pb.act(d.data_ptr(), 4, d.data_ptr(), action_string="+x")

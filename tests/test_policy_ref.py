@@ -1,0 +1,96 @@
+"""CPU checks of the policy-network side: the batched fp32 reference against the per-agent module
+built like the reference's libtorch model, the ABI surface of include/strikeforce_policy.h, and the no-GPU behaviour."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from strikeforce_amd import build, env, policy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import policy_ref  # noqa: E402
+
+
+def _obs(rng, B):
+    """Observation-like input: mostly zeros, values of the encoder's magnitude (|x|/10)^0.2 with signs."""
+    x = rng.uniform(0.0, 2.0, size=(B, 32, 31, 31)).astype(np.float32)
+    x *= rng.uniform(size=x.shape) < 0.3
+    x *= np.where(rng.uniform(size=x.shape) < 0.2, -1.0, 1.0).astype(np.float32)
+    return x
+
+
+def test_parameter_names_match_the_module():
+    m = policy_ref.AgentModel()
+    sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert sd == {k: tuple(v) for k, v in policy.parameter_shapes().items()}
+    # 48.6 MFLOP per agent forward in the four convolutions alone
+    n = sum(int(np.prod(s)) for s in sd.values())
+    assert n == 160 * 32 * 9 + 3 * 160 * 160 * 9 + 2 * (2 * 480 * 160 + 2 * 480) + 160 * 329 + 160 + 2 * 3 * (160 * 160 + 160) + 160 + 1 + 9 * 160 + 9
+
+
+def test_batched_reference_equals_per_agent_module():
+    rng = np.random.default_rng(5)
+    params = policy.init_parameters(seed=11)
+    B, T = 3, 4
+    models = [policy_ref.model_from_parameters(params) for _ in range(B)]
+    h = np.zeros((2, B, 160), dtype=np.float32)
+    a = np.zeros((B, 9), dtype=np.float32)
+    a[:, 0] = 1
+    with torch.no_grad():
+        for t in range(T):
+            obs = _obs(rng, B)
+            probs, value, h = policy_ref.forward_batched(params, obs, h, a)
+            for b in range(B):
+                p, v = models[b](torch.from_numpy(obs[b:b + 1]))
+                np.testing.assert_allclose(p.numpy(), probs[b], rtol=2e-5, atol=1e-7)
+                np.testing.assert_allclose(v.numpy()[0], value[b], rtol=2e-5, atol=1e-7)
+                np.testing.assert_allclose(models[b].backbone.h_state[0].view(-1).numpy(), h[0, b], rtol=2e-5, atol=1e-6)
+                np.testing.assert_allclose(models[b].backbone.h_state[1].view(-1).numpy(), h[1, b], rtol=2e-5, atol=1e-6)
+                act = int(rng.integers(0, 9))
+                one = torch.zeros(9)
+                one[act] += 1
+                models[b].update_actions(one)
+                a[b] = one.numpy()
+    assert np.all(np.abs(probs.sum(axis=1) - 1) < 1e-5)
+
+
+def test_action_weights_follow_predict():
+    p = np.array([0.2, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1], dtype=np.float32)
+    v = policy_ref.action_weights(p)
+    assert v[0] == np.float32(0.5)
+    np.testing.assert_allclose(v[1:].sum(), 0.5, rtol=1e-4)  # the eight moves share the other half
+
+
+def test_policy_library_exports_header_symbols():
+    build.build(verbose=False)
+    L = env.load_library()
+    header = open(os.path.join(ROOT, "include", "strikeforce_policy.h")).read()
+    declared = set(re.findall(r"\b(sf_policy_[a-z_]+)\s*\(", header))
+    assert declared == set(policy.EXPORTS), declared ^ set(policy.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    policy._bind(L)
+    assert L.sf_policy_abi_version() == policy.POLICY_ABI_VERSION
+    assert C.sizeof(policy.Weights) == 8 + 8 * (4 + 8 + 2 + 8 + 8)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_policy_refuses_to_run_without_a_gpu():
+    with pytest.raises(env.StrikeForceError, match="no HIP device|hip"):
+        policy.PolicyBatch(policy.init_parameters(0), 4)
+
+
+def test_policy_rejects_bad_parameters():
+    params = policy.init_parameters(0)
+    bad = dict(params)
+    bad["value.1.weight"] = np.zeros((2, 160), dtype=np.float32)
+    with pytest.raises(ValueError, match="shape"):
+        policy.PolicyBatch(bad, 4)
+    del bad["value.1.weight"]
+    with pytest.raises(ValueError, match="missing"):
+        policy.PolicyBatch(bad, 4)
