@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: f32-input MFMA (v_mfma_f32_32x32x2_f32), dense
 
 
 def algorithmic_bytes_per_step(cfg, observe=False):
@@ -78,6 +79,7 @@ def main():
     ap.add_argument("--k-per-launch", type=int, default=50, help="loop iterations per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-interactive", action="store_true", help="skip the K=1 + observation measurement")
+    ap.add_argument("--no-policy", action="store_true", help="skip the closed loop with the on-device policy network")
     args = ap.parse_args()
 
     import torch
@@ -179,6 +181,39 @@ def main():
         host_ms = (time.perf_counter() - t1) * 1e3 / obs_n
     g.kernel_time(False)
 
+    # the closed loop with the reference's bot network evaluated on the device:
+    # observe -> sf_policy_forward -> sf_policy_act -> K=1 step, nothing leaves HBM
+    pol = None
+    if obs_n and not args.no_policy:
+        from strikeforce_amd import policy
+        agents = args.arenas * cfg.n_agents
+        pb = policy.PolicyBatch(policy.init_parameters(seed=0), agents, device=local)
+        pb.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_probs = torch.empty(agents * 9, dtype=torch.float32, device="cuda")
+        d_value = torch.empty(agents, dtype=torch.float32, device="cuda")
+        d_pcmd = torch.zeros(agents, dtype=torch.uint8, device="cuda")
+        pol_n = 10
+
+        def closed_loop(n):
+            for _ in range(n):
+                g.observe_device(d_obs.data_ptr())
+                pb.forward(d_obs.data_ptr(), agents, d_probs.data_ptr(), d_value.data_ptr())
+                pb.act(d_probs.data_ptr(), agents, d_pcmd.data_ptr(), seed=rank)
+                g.step_device(d_pcmd.data_ptr(), 1)
+
+        closed_loop(2)
+        torch.cuda.synchronize()
+        pb.kernel_time(True)
+        pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        pe[0].record()
+        closed_loop(pol_n)
+        pe[1].record()
+        torch.cuda.synchronize()
+        g_ms, g_flop, g_n = pb.kernel_time(False)
+        pol = {"loop_ms": pe[0].elapsed_time(pe[1]) / pol_n, "gemm_ms": g_ms / pol_n, "gemm_flop": g_flop / pol_n,
+               "gemm_launches": g_n // pol_n, "steps": pol_n, "agents": agents}
+        pb.close()
+
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -225,6 +260,16 @@ def main():
                                      "unit": "GB/s", "frac": obs_bytes / (obs_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                                      "algorithmic_bytes_per_agent_step": 30752 * 4 + 961 * 8},
           }
+        if pol:
+            tf = pol["gemm_flop"] / (pol["gemm_ms"] / 1e3) / 1e12
+            out["policy"] = {
+                "what": "per rank: observe -> bot-0.5 network (f32 MFMA, random-init weights) -> sample -> K=1 step, "
+                        "all on device, %d steps" % pol["steps"],
+                "agent_steps_per_s": world * pol["agents"] / (pol["loop_ms"] / 1e3), "ms_per_step": pol["loop_ms"],
+                "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / MFMA_F32_PEAK_TFLOPS, "kernel": "k_gemm (%d launches per forward)" % pol["gemm_launches"],
+                             "gemm_ms_per_forward": pol["gemm_ms"], "flop_per_agent_forward": pol["gemm_flop"] / pol["agents"]},
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -85,6 +85,12 @@ int sf_policy_synchronize(sf_policy *p);
  * (2*M*N*K each), *launches = how many. */
 int sf_policy_kernel_time(sf_policy *p, int32_t enable, float *ms, double *flop, int32_t *launches);
 
+/* The matrix kernel on its own, for unit tests and roofline measurements: C[M][ldc] = A[M][lda] * W[N][K]^T + bias
+ * (bias may be NULL), all device pointers, f32; K % 32 == 0, N % 160 == 0, lda % 4 == 0.  Every Linear / GRU gate
+ * product of the network goes through this path; the convolutions use the same kernel with an im2col gather. */
+int sf_policy_gemm(sf_policy *p, const float *d_a, int32_t lda, const float *d_w, const float *d_bias, float *d_c,
+                   int32_t ldc, int32_t m, int32_t n, int32_t k);
+
 int sf_policy_abi_version(void);
 
 #ifdef __cplusplus

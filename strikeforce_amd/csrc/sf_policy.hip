@@ -11,7 +11,8 @@
 //
 // Kernels
 //   k_gemm<WAVES, MODE>   C[M][N] = A[M][K] * W[N][K]^T (+ bias), LDS-tiled, 32 rows x 160 columns per wave
-//                         (5 accumulator tiles of 32x32), BK = 16, register prefetch + double-buffered LDS.
+//                         (5 accumulator tiles of 32x32; or 5 waves x 1 tile when M is small), K tile 16 or 32,
+//                         global->register prefetch, double-buffered LDS, operand fragments read one product ahead.
 //                         MODE selects how a row of A is addressed: a dense row, or the im2col row of a 3x3/stride-2
 //                         convolution gathered on the fly from an NHWC activation (conv1..3) or from the NCHW
 //                         observation buffer (conv0).  Activations between the convolutions are kept NHWC, which is
@@ -41,7 +42,7 @@ constexpr int OBS_W = SF_OBS_WINDOW;     // 31
 constexpr int OBS_F = SF_OBS_FLOATS;     // 30752
 constexpr int POV = SF_POLICY_POV;       // 169
 constexpr int COMB = 2 * HID + ACT;      // 329 inputs of combined_processor
-constexpr int COMB_PAD = 336;            // padded to a multiple of the GEMM's K tile
+constexpr int COMB_PAD = 352;            // padded to a multiple of the GEMM's K tiles (16 and 32)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -53,72 +54,90 @@ struct Gemm {
   const float *W;     // [N][K] row-major
   const float *bias;  // [N] or null
   float *C;           // [M][ldc]
-  int M, N, K;        // K % 16 == 0, N % 160 == 0
+  int M, N, K;        // K % 32 == 0, N % 160 == 0
   int lda, ldc;
   int S, Cin, So;     // convolution modes: input side, input channels, output side
+  int dbg;
 };
 
-constexpr int BN = 160, BK = 16, LD = BK + 1;
+constexpr int BN = 160;
 
 __device__ inline f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
-template <int WAVES, int MODE>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm(Gemm g) {
-  constexpr int T = WAVES * 64, BM = WAVES * 32;
-  constexpr int RP = T / 4;                    // rows covered by one pass of float4 loads
-  constexpr int AJ = BM / RP;                  // = 2
-  constexpr int BJ = (BN + RP - 1) / RP;       // 3, 5 or 10
-  constexpr int SJ = BK / (T / BM);            // scalar (NCHW) loads per thread = 8
+// Block tile (WM*32) x 160, K tile BKT.  WN = 1: a wave owns 32 rows x 160 columns (5 accumulator tiles; the
+// large-M shape).  WN = 5: the five 32-column tiles of the same 32 rows go to five waves (the small-M shape: five
+// times the waves for the same work, each with a fifth of the dependent MFMA chain).
+template <int WM, int WN, int BKT, int MODE>
+__global__ __launch_bounds__(WM *WN * 64, (WN == 1 && BKT == 16) ? 3 : 1) void k_gemm(Gemm g) {
+  constexpr int T = WM * WN * 64, BM = WM * 32, LD = BKT + 1;
+  constexpr int NT = 5 / WN;                    // 32-column tiles per wave
+  constexpr int Q = BKT / 4;                    // float4 per tile row
+  constexpr int AJ = (BM * Q + T - 1) / T;      // float4 loads of A per thread
+  constexpr int BJ = (BN * Q + T - 1) / T;      // float4 loads of W per thread
+  constexpr int SJ = (BM * BKT + T - 1) / T;    // scalar loads of A per thread (NCHW gather)
+  constexpr int KS = BKT / 2;                   // 32x32x2 products per tile
   __shared__ float As[2][BM * LD];
   __shared__ float Bs[2][BN * LD];
 
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int wm = w / WN, wn = w - wm * WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int KT = g.K / BK;
+  const int KT = g.K / BKT;
 
   // ---- where this thread's share of the A tile comes from ----
   const float *arow[AJ];
-  const float *acol = nullptr;  // NCHW: one row per thread
+  // NCHW: consecutive threads walk consecutive rows, one row per thread.  The address is split into a wave-uniform
+  // part (the block's first agent + the (cin, ky, kx) offset of the k being loaded: SALU, lands in the load's saddr)
+  // and a 32-bit per-lane part (this row's pixel relative to that agent), so a gathered element costs no VALU.
+  const float *abase = nullptr;
+  uint32_t avoff = 0;
   if (MODE == MODE_NCHW) {
     int m = m0 + (t % BM);
     if (m >= g.M) m = g.M - 1;
     const int so2 = g.So * g.So;
+    const int b0 = m0 / so2;
     const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
-    acol = g.A + (size_t)b * g.Cin * g.S * g.S + (size_t)(2 * oy) * g.S + 2 * ox;
+    abase = g.A + (size_t)b0 * g.Cin * g.S * g.S;
+    avoff = (uint32_t)(((b - b0) * g.Cin * g.S * g.S + (2 * oy) * g.S + 2 * ox) * 4);
   } else {
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      int m = m0 + t / 4 + j * RP;
+      const int f = t + j * T;
+      int m = m0 + ((f / Q < BM) ? f / Q : BM - 1);
       if (m >= g.M) m = g.M - 1;
       if (MODE == MODE_DENSE) {
-        arow[j] = g.A + (size_t)m * g.lda + (t & 3) * 4;
+        arow[j] = g.A + (size_t)m * g.lda + (f % Q) * 4;
       } else {
         const int so2 = g.So * g.So;
         const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
-        arow[j] = g.A + ((size_t)(b * g.S + 2 * oy) * g.S + 2 * ox) * g.Cin + (t & 3) * 4;
+        arow[j] = g.A + ((size_t)(b * g.S + 2 * oy) * g.S + 2 * ox) * g.Cin + (f % Q) * 4;
       }
     }
   }
   const float *brow[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    int n = t / 4 + j * RP;
-    if (n >= BN) n = BN - 1;
-    brow[j] = g.W + (size_t)(n0 + n) * g.K + (t & 3) * 4;
+    const int f = t + j * T;
+    const int n = (f / Q < BN) ? f / Q : BN - 1;
+    brow[j] = g.W + (size_t)(n0 + n) * g.K + (f % Q) * 4;
   }
 
   f32x4 ra[AJ], rb[BJ];
   float rs[SJ];
 
   auto gload = [&](int kt) {
-    const int k0 = kt * BK;
+    const int k0 = kt * BKT;
     if (MODE == MODE_NCHW) {
       const int ss = g.S * g.S;
 #pragma unroll
       for (int j = 0; j < SJ; ++j) {
-        const int k = k0 + t / BM + j * (T / BM);
+        const int e = t + j * T;
+        int kl = (e / BM < BKT) ? e / BM : BKT - 1;
+        if (BM % 64 == 0) kl = __builtin_amdgcn_readfirstlane(kl);  // a wave's 64 rows share k
+        const int k = k0 + kl;
         const int cin = k / 9, tap = k - cin * 9, ky = tap / 3, kx = tap - ky * 3;
-        rs[j] = acol[(size_t)cin * ss + ky * g.S + kx];
+        const char *sb = reinterpret_cast<const char *>(abase + ((size_t)cin * ss + ky * g.S + kx));
+        rs[j] = *reinterpret_cast<const float *>(sb + avoff);
       }
     } else {
       int off = k0;
@@ -135,59 +154,91 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm(Gemm g) {
   auto lstore = [&](int buf) {
     if (MODE == MODE_NCHW) {
 #pragma unroll
-      for (int j = 0; j < SJ; ++j) As[buf][(t % BM) * LD + t / BM + j * (T / BM)] = rs[j];
+      for (int j = 0; j < SJ; ++j) {
+        const int e = t + j * T;
+        if ((BM * BKT) % T == 0 || e < BM * BKT) As[buf][(e % BM) * LD + e / BM] = rs[j];
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
-        float *d = &As[buf][(t / 4 + j * RP) * LD + (t & 3) * 4];
-        d[0] = ra[j].x, d[1] = ra[j].y, d[2] = ra[j].z, d[3] = ra[j].w;
+        const int f = t + j * T;
+        if ((BM * Q) % T == 0 || f < BM * Q) {
+          float *d = &As[buf][(f / Q) * LD + (f % Q) * 4];
+          d[0] = ra[j].x, d[1] = ra[j].y, d[2] = ra[j].z, d[3] = ra[j].w;
+        }
       }
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const int n = t / 4 + j * RP;
-      if (n < BN) {
-        float *d = &Bs[buf][n * LD + (t & 3) * 4];
+      const int f = t + j * T;
+      if ((BN * Q) % T == 0 || f < BN * Q) {
+        float *d = &Bs[buf][(f / Q) * LD + (f % Q) * 4];
         d[0] = rb[j].x, d[1] = rb[j].y, d[2] = rb[j].z, d[3] = rb[j].w;
       }
     }
   };
 
-  f32x16 acc[5];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  // Schedule of one K tile (the compiler is held to it with sched_barrier): the tile's products run in GS groups of
+  // two (k, k+2 -> one ds_read2_b32 per operand); the fragments of group i+1 are read from LDS before the MFMAs of
+  // group i issue.  Half-way through, the next tile (in registers since the previous tile) is written to the other
+  // LDS buffer and the loads of the tile after it are issued; the block's only barrier comes before the last
+  // group, followed by the read of the next tile's first fragments, so both hide behind that group's MFMAs.
+  constexpr int GS = KS / 2;
+  float fa[2][2], fb[2][NT][2];
+  auto fload = [&](int buf, int grp, int slot) {
+    const float *as = &As[buf][(wm * 32 + (l & 31)) * LD + (l >> 5)];
+    const float *bs = &Bs[buf][(wn * NT * 32 + (l & 31)) * LD + (l >> 5)];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      fa[slot][h] = as[4 * grp + 2 * h];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[slot][nt][h] = bs[nt * 32 * LD + 4 * grp + 2 * h];
+    }
+  };
   gload(0);
   lstore(0);
   __syncthreads();
+  if (KT > 1) gload(1);
+  fload(0, 0, 0);
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < KT) gload(kt + 1);
-    // lane l feeds A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31] of each 32x32x2 product
-    const float *as = &As[buf][(w * 32 + (l & 31)) * LD + (l >> 5)];
-    const float *bs = &Bs[buf][(l & 31) * LD + (l >> 5)];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a = as[kk];
+    for (int grp = 0; grp < GS; ++grp) {
+      if (grp == GS / 2 && kt + 1 < KT) {
+        if (!(g.dbg & 4)) lstore(buf ^ 1);
+        if (kt + 2 < KT && !(g.dbg & 2)) gload(kt + 2);
+      }
+      if (grp + 1 < GS) {
+        fload(buf, grp + 1, (grp + 1) & 1);
+      } else if (kt + 1 < KT) {
+        if (!(g.dbg & 8)) __syncthreads();
+        fload(buf ^ 1, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int nt = 0; nt < 5; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[nt * 32 * LD + kk], acc[nt], 0, 0, 0);
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[grp & 1][h], fb[grp & 1][nt][h], acc[nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt + 1 < KT) lstore(buf ^ 1);
-    __syncthreads();
   }
 
   // C/D map of the 32x32 tile: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
 #pragma unroll
-  for (int nt = 0; nt < 5; ++nt) {
-    const int n = n0 + nt * 32 + (l & 31);
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + (wn * NT + nt) * 32 + (l & 31);
     const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-      if (m < g.M) g.C[(size_t)m * g.ldc + n] = acc[nt][r] + bv;
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      if (m < g.M && (!(g.dbg & 1) || acc[nt][r] == 12345.678f)) g.C[(size_t)m * g.ldc + n] = acc[nt][r] + bv;
     }
   }
 }
@@ -252,7 +303,7 @@ __global__ __launch_bounds__(256) void k_norm(const float *x, float *y, int agen
 }
 
 // gru0 + the assembly of `combined` (Modules.hpp:110-123): comb[0:160] = norm(h0') + feat_n,
-// comb[160:329] = norm(pov), comb[329:336] = 0 (K padding)
+// comb[160:329] = norm(pov), comb[329:352] = 0 (K padding)
 __global__ __launch_bounds__(256) void k_gru0(const float *gi, const float *gh, float *h, const float *feat_n,
                                               const float *obs, const float *action_input, float *comb, int agents) {
   SFP_ROW_PROLOGUE
@@ -451,19 +502,21 @@ struct Policy {
     return SF_OK;
   }
 
-  template <int WAVES, int MODE>
+  template <int WM, int WN, int BKT, int MODE>
   void launch_t(const Gemm &g) {
-    dim3 grid((unsigned)((g.M + WAVES * 32 - 1) / (WAVES * 32)), (unsigned)(g.N / BN));
-    hipLaunchKernelGGL((k_gemm<WAVES, MODE>), grid, dim3(WAVES * 64), 0, stream, g);
+    dim3 grid((unsigned)((g.M + WM * 32 - 1) / (WM * 32)), (unsigned)(g.N / BN));
+    size_t dyn = getenv("SF_POLICY_DYN") ? (size_t)atoi(getenv("SF_POLICY_DYN")) : 0;
+    if (dyn) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm<WM, WN, BKT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipLaunchKernelGGL((k_gemm<WM, WN, BKT, MODE>), grid, dim3(WM * WN * 64), dyn, stream, g);
   }
   template <int MODE>
   void launch_m(const Gemm &g) {
-    if (g.M >= 65536) launch_t<4, MODE>(g);
-    else if (g.M >= 16384) launch_t<2, MODE>(g);
-    else launch_t<1, MODE>(g);
+    if (g.M >= 65536) launch_t<4, 1, 16, MODE>(g);
+    else if (g.M >= 16384) launch_t<2, 1, 32, MODE>(g);
+    else launch_t<1, 5, 32, MODE>(g);
   }
   int gemm(const Gemm &g, int mode) {
-    if (g.K % BK || g.N % BN || g.M < 1) return fail(SF_ERR_ARG, "policy gemm: unsupported shape");
+    if (g.K % 32 || g.N % BN || g.M < 1) return fail(SF_ERR_ARG, "policy gemm: unsupported shape");
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) {
       if (used_events == events.size()) {
@@ -487,12 +540,12 @@ struct Policy {
     return SF_OK;
   }
   int dense(const float *A, int lda, const float *W, const float *bias, float *C, int ldc, int M, int N, int K) {
-    Gemm g{A, W, bias, C, M, N, K, lda, ldc, 0, 0, 0};
+    Gemm g{A, W, bias, C, M, N, K, lda, ldc, 0, 0, 0, getenv("SF_POLICY_DBG") ? atoi(getenv("SF_POLICY_DBG")) : 0};
     return gemm(g, MODE_DENSE);
   }
   int conv(const float *in, const float *W, float *outp, int agents, int S, int Cin, int nchw) {
     const int So = (S - 3) / 2 + 1;
-    Gemm g{in, W, nullptr, outp, agents * So * So, HID, Cin * 9, 0, HID, S, Cin, So};
+    Gemm g{in, W, nullptr, outp, agents * So * So, HID, Cin * 9, 0, HID, S, Cin, So, 0};
     return gemm(g, nchw ? MODE_NCHW : MODE_NHWC);
   }
 };
@@ -659,6 +712,15 @@ int sf_policy_act(sf_policy *pp, const float *d_probs, int32_t agents, const cha
                      p->action_input, as, seed, p->draws++, greedy, d_cmd, d_action, agents);
   SFP_HIP(hipGetLastError());
   return SF_OK;
+}
+
+int sf_policy_gemm(sf_policy *pp, const float *d_a, int32_t lda, const float *d_w, const float *d_bias, float *d_c,
+                   int32_t ldc, int32_t m, int32_t n, int32_t k) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p || !d_a || !d_w || !d_c) return sfp::fail(SF_ERR_ARG, "null argument");
+  if (lda % 4 || lda < k || ldc < n) return sfp::fail(SF_ERR_ARG, "policy gemm: bad leading dimension");
+  SFP_HIP(hipSetDevice(p->device));
+  return p->dense(d_a, lda, d_w, d_bias, d_c, ldc, m, n, k);
 }
 
 int sf_policy_get_memory(sf_policy *pp, int32_t agent, float *h, float *action_input) {
