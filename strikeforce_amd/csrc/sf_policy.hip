@@ -57,18 +57,33 @@ struct Gemm {
   int M, N, K;        // K % 32 == 0, N % 160 == 0
   int lda, ldc;
   int S, Cin, So;     // convolution modes: input side, input channels, output side
-  int dbg;
+  // work split: the (row tile, K tile) units of one 160-column strip, numbered tile-major, are dealt to the
+  // gridDim.x blocks in contiguous runs of unit_base (+1 for the first unit_rem blocks) units
+  int ntiles, unit_base, unit_rem;
+  float *part;        // [gridDim.y][gridDim.x][2][BM*160] partial tiles of runs that start or end inside a tile
 };
 
 constexpr int BN = 160;
 
 __device__ inline f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
+__device__ inline int run_start(const Gemm &g, int b) { return b * g.unit_base + (b < g.unit_rem ? b : g.unit_rem); }
+__device__ inline int run_owner(const Gemm &g, int u) {
+  const int big = g.unit_rem * (g.unit_base + 1);
+  return u < big ? u / (g.unit_base + 1) : g.unit_rem + (u - big) / g.unit_base;
+}
+
 // Block tile (WM*32) x 160, K tile BKT.  WN = 1: a wave owns 32 rows x 160 columns (5 accumulator tiles; the
 // large-M shape).  WN = 5: the five 32-column tiles of the same 32 rows go to five waves (the small-M shape: five
 // times the waves for the same work, each with a fifth of the dependent MFMA chain).
+//
+// A block walks a contiguous run of (row tile, K tile) units ("stream-K"): with one tile per run this is the
+// classic one-block-per-tile GEMM; with gridDim.x = the number of resident blocks the chip holds, every block gets
+// the same number of MFMAs whatever M is, the global->LDS->MFMA pipeline never drains between row tiles, and a tile
+// whose K range is cut by a run boundary is finished by k_gemm_fixup, which adds the partial tiles in K order
+// (deterministic: no atomics).
 template <int WM, int WN, int BKT, int MODE>
-__global__ __launch_bounds__(WM *WN * 64, (WN == 1 && BKT == 16) ? 3 : 1) void k_gemm(Gemm g) {
+__global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm(Gemm g) {
   constexpr int T = WM * WN * 64, BM = WM * 32, LD = BKT + 1;
   constexpr int NT = 5 / WN;                    // 32-column tiles per wave
   constexpr int Q = BKT / 4;                    // float4 per tile row
@@ -76,44 +91,51 @@ __global__ __launch_bounds__(WM *WN * 64, (WN == 1 && BKT == 16) ? 3 : 1) void k
   constexpr int BJ = (BN * Q + T - 1) / T;      // float4 loads of W per thread
   constexpr int SJ = (BM * BKT + T - 1) / T;    // scalar loads of A per thread (NCHW gather)
   constexpr int KS = BKT / 2;                   // 32x32x2 products per tile
+  constexpr int GS = KS / 2;                    // groups of two products
   __shared__ float As[2][BM * LD];
   __shared__ float Bs[2][BN * LD];
 
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
   const int wm = w / WN, wn = w - wm * WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int n0 = blockIdx.y * BN;
   const int KT = g.K / BKT;
+  const int u0 = run_start(g, blockIdx.x);
+  const int nu = g.unit_base + ((int)blockIdx.x < g.unit_rem ? 1 : 0);
+  if (nu == 0) return;
 
-  // ---- where this thread's share of the A tile comes from ----
+  // ---- where this thread's share of an A tile comes from (recomputed when the load cursor enters a new row tile) ----
   const float *arow[AJ];
   // NCHW: consecutive threads walk consecutive rows, one row per thread.  The address is split into a wave-uniform
-  // part (the block's first agent + the (cin, ky, kx) offset of the k being loaded: SALU, lands in the load's saddr)
+  // part (the tile's first agent + the (cin, ky, kx) offset of the k being loaded: SALU, lands in the load's saddr)
   // and a 32-bit per-lane part (this row's pixel relative to that agent), so a gathered element costs no VALU.
   const float *abase = nullptr;
   uint32_t avoff = 0;
-  if (MODE == MODE_NCHW) {
-    int m = m0 + (t % BM);
-    if (m >= g.M) m = g.M - 1;
-    const int so2 = g.So * g.So;
-    const int b0 = m0 / so2;
-    const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
-    abase = g.A + (size_t)b0 * g.Cin * g.S * g.S;
-    avoff = (uint32_t)(((b - b0) * g.Cin * g.S * g.S + (2 * oy) * g.S + 2 * ox) * 4);
-  } else {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const int f = t + j * T;
-      int m = m0 + ((f / Q < BM) ? f / Q : BM - 1);
+  auto setrow = [&](int tile) {
+    const int m0 = tile * BM;
+    if (MODE == MODE_NCHW) {
+      int m = m0 + (t % BM);
       if (m >= g.M) m = g.M - 1;
-      if (MODE == MODE_DENSE) {
-        arow[j] = g.A + (size_t)m * g.lda + (f % Q) * 4;
-      } else {
-        const int so2 = g.So * g.So;
-        const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
-        arow[j] = g.A + ((size_t)(b * g.S + 2 * oy) * g.S + 2 * ox) * g.Cin + (f % Q) * 4;
+      const int so2 = g.So * g.So;
+      const int b0 = m0 / so2;
+      const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
+      abase = g.A + (size_t)b0 * g.Cin * g.S * g.S;
+      avoff = (uint32_t)(((b - b0) * g.Cin * g.S * g.S + (2 * oy) * g.S + 2 * ox) * 4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int f = t + j * T;
+        int m = m0 + ((f / Q < BM) ? f / Q : BM - 1);
+        if (m >= g.M) m = g.M - 1;
+        if (MODE == MODE_DENSE) {
+          arow[j] = g.A + (size_t)m * g.lda + (f % Q) * 4;
+        } else {
+          const int so2 = g.So * g.So;
+          const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
+          arow[j] = g.A + ((size_t)(b * g.S + 2 * oy) * g.S + 2 * ox) * g.Cin + (f % Q) * 4;
+        }
       }
     }
-  }
+  };
   const float *brow[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
@@ -179,17 +201,37 @@ __global__ __launch_bounds__(WM *WN * 64, (WN == 1 && BKT == 16) ? 3 : 1) void k
   };
 
   f32x16 acc[NT];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  };
+  // C/D map of the 32x32 tile: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+  auto flush = [&](int tile, bool whole, int slot) {
+    const int m0 = tile * BM;
+    float *pt = g.part + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + slot) * (BM * BN);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int nl = (wn * NT + nt) * 32 + (l & 31);
+      const float bv = (whole && g.bias) ? g.bias[n0 + nl] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (whole) {
+          if (m0 + ml < g.M) g.C[(size_t)(m0 + ml) * g.ldc + n0 + nl] = acc[nt][r] + bv;
+        } else {
+          pt[ml * BN + nl] = acc[nt][r];
+        }
+      }
+    }
+  };
 
-  // Schedule of one K tile (the compiler is held to it with sched_barrier): the tile's products run in GS groups of
+  // Schedule of one unit (the compiler is held to it with sched_barrier): the unit's products run in GS groups of
   // two (k, k+2 -> one ds_read2_b32 per operand); the fragments of group i+1 are read from LDS before the MFMAs of
-  // group i issue.  Half-way through, the next tile (in registers since the previous tile) is written to the other
-  // LDS buffer and the loads of the tile after it are issued; the block's only barrier comes before the last
-  // group, followed by the read of the next tile's first fragments, so both hide behind that group's MFMAs.
-  constexpr int GS = KS / 2;
+  // group i issue.  Half-way through, the next unit (in registers since the previous unit) is written to the other
+  // LDS buffer and the loads of the unit after it are issued; the block's only barrier comes before the last
+  // group, followed by the read of the next unit's first fragments, so both hide behind that group's MFMAs.
   float fa[2][2], fb[2][NT][2];
   auto fload = [&](int buf, int grp, int slot) {
     const float *as = &As[buf][(wm * 32 + (l & 31)) * LD + (l >> 5)];
@@ -201,23 +243,38 @@ __global__ __launch_bounds__(WM *WN * 64, (WN == 1 && BKT == 16) ? 3 : 1) void k
       for (int nt = 0; nt < NT; ++nt) fb[slot][nt][h] = bs[nt * 32 * LD + 4 * grp + 2 * h];
     }
   };
-  gload(0);
+
+  // load cursor (two units ahead of the MFMAs) and compute cursor
+  int tile_l = u0 / KT, kt_l = u0 - tile_l * KT;
+  int tile_c = tile_l, kt_c = kt_l, seg_kt0 = kt_l;
+  bool seg_first = true;
+  auto load_next = [&]() {
+    gload(kt_l);
+    if (++kt_l == KT) {
+      kt_l = 0;
+      ++tile_l;
+      if (tile_l < g.ntiles) setrow(tile_l);
+    }
+  };
+  setrow(tile_l);
+  load_next();
   lstore(0);
   __syncthreads();
-  if (KT > 1) gload(1);
+  if (nu > 1) load_next();
   fload(0, 0, 0);
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
+  zero_acc();
+  for (int i = 0; i < nu; ++i) {
+    const int buf = i & 1;
 #pragma unroll
     for (int grp = 0; grp < GS; ++grp) {
-      if (grp == GS / 2 && kt + 1 < KT) {
-        if (!(g.dbg & 4)) lstore(buf ^ 1);
-        if (kt + 2 < KT && !(g.dbg & 2)) gload(kt + 2);
+      if (grp == GS / 2 && i + 1 < nu) {
+        lstore(buf ^ 1);
+        if (i + 2 < nu) load_next();
       }
       if (grp + 1 < GS) {
         fload(buf, grp + 1, (grp + 1) & 1);
-      } else if (kt + 1 < KT) {
-        if (!(g.dbg & 8)) __syncthreads();
+      } else if (i + 1 < nu) {
+        __syncthreads();
         fload(buf ^ 1, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -228,17 +285,44 @@ __global__ __launch_bounds__(WM *WN * 64, (WN == 1 && BKT == 16) ? 3 : 1) void k
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[grp & 1][h], fb[grp & 1][nt][h], acc[nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (kt_c == KT - 1 || i == nu - 1) {
+      flush(tile_c, seg_kt0 == 0 && kt_c == KT - 1, seg_first ? 0 : 1);
+      zero_acc();
+      seg_first = false;
+      seg_kt0 = 0;
+    }
+    if (++kt_c == KT) kt_c = 0, ++tile_c;
   }
+}
 
-  // C/D map of the 32x32 tile: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+// Finishes the row tiles whose K range was cut by a run boundary: C = bias + the partial tiles in K order.  One
+// block per run boundary; the boundary that is the first one inside its tile does the tile.
+template <int BM>
+__global__ __launch_bounds__(256) void k_gemm_fixup(Gemm g, int KT, int G) {
+  const int b_lo = blockIdx.x, n0 = blockIdx.y * BN;
+  const int cut = run_start(g, b_lo + 1);  // first unit of the next run
+  if (cut % KT == 0) return;               // the boundary coincides with a tile boundary
+  const int tile = cut / KT, ua = tile * KT;
+  if (run_owner(g, ua) != b_lo) return;    // an earlier boundary inside the same tile owns it
+  const int b_hi = run_owner(g, ua + KT - 1);
+  const int m0 = tile * BM;
+  constexpr int V = BM * BN / 4 / 256;     // float4 per thread
+  f32x4 s[V];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + (wn * NT + nt) * 32 + (l & 31);
-    const float bv = g.bias ? g.bias[n] : 0.f;
+  for (int j = 0; j < V; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = b_lo; b <= b_hi; ++b) {
+    const int slot = run_start(g, b) >= ua ? 0 : 1;  // a run's first segment is in slot 0, a later one in slot 1
+    const float *pt = g.part + (((size_t)blockIdx.y * G + b) * 2 + slot) * (BM * BN);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-      if (m < g.M && (!(g.dbg & 1) || acc[nt][r] == 12345.678f)) g.C[(size_t)m * g.ldc + n] = acc[nt][r] + bv;
+    for (int j = 0; j < V; ++j) s[j] += ldg4(pt + (threadIdx.x + 256 * j) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int e = (threadIdx.x + 256 * j) * 4, ml = e / BN, nl = e - ml * BN;
+    if (m0 + ml < g.M) {
+      f32x4 v = s[j];
+      if (g.bias) v += ldg4(g.bias + n0 + nl);
+      *reinterpret_cast<f32x4 *>(g.C + (size_t)(m0 + ml) * g.ldc + n0 + nl) = v;
     }
   }
 }
@@ -502,17 +586,26 @@ struct Policy {
     return SF_OK;
   }
 
+  // Resident blocks of the large-M shape: its 76 KB of LDS pins two 4-wave blocks on each CU (set in create())
+  int sk_blocks = 512;
+  float *part = nullptr;  // [sk_blocks][2][128*160]
+
   template <int WM, int WN, int BKT, int MODE>
-  void launch_t(const Gemm &g) {
-    dim3 grid((unsigned)((g.M + WM * 32 - 1) / (WM * 32)), (unsigned)(g.N / BN));
-    size_t dyn = getenv("SF_POLICY_DYN") ? (size_t)atoi(getenv("SF_POLICY_DYN")) : 0;
-    if (dyn) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm<WM, WN, BKT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    hipLaunchKernelGGL((k_gemm<WM, WN, BKT, MODE>), grid, dim3(WM * WN * 64), dyn, stream, g);
+  void launch_t(Gemm g) {
+    const int BM = WM * 32, KT = g.K / BKT;
+    g.ntiles = (g.M + BM - 1) / BM;
+    g.part = part;
+    const long units = (long)g.ntiles * KT;
+    int G = g.ntiles;  // one run per row tile: the classic decomposition
+    if (WN == 1 && g.N == BN && units >= 4L * sk_blocks) G = sk_blocks;
+    g.unit_base = (int)(units / G), g.unit_rem = (int)(units % G);
+    hipLaunchKernelGGL((k_gemm<WM, WN, BKT, MODE>), dim3((unsigned)G, (unsigned)(g.N / BN)), dim3(WM * WN * 64), 0, stream, g);
+    if (G != g.ntiles)
+      hipLaunchKernelGGL((k_gemm_fixup<WM * 32>), dim3((unsigned)(G - 1), (unsigned)(g.N / BN)), dim3(256), 0, stream, g, KT, G);
   }
   template <int MODE>
   void launch_m(const Gemm &g) {
-    if (g.M >= 65536) launch_t<4, 1, 16, MODE>(g);
-    else if (g.M >= 16384) launch_t<2, 1, 32, MODE>(g);
+    if (g.M >= 16384) launch_t<4, 1, 32, MODE>(g);
     else launch_t<1, 5, 32, MODE>(g);
   }
   int gemm(const Gemm &g, int mode) {
@@ -540,12 +633,12 @@ struct Policy {
     return SF_OK;
   }
   int dense(const float *A, int lda, const float *W, const float *bias, float *C, int ldc, int M, int N, int K) {
-    Gemm g{A, W, bias, C, M, N, K, lda, ldc, 0, 0, 0, getenv("SF_POLICY_DBG") ? atoi(getenv("SF_POLICY_DBG")) : 0};
+    Gemm g{A, W, bias, C, M, N, K, lda, ldc, 0, 0, 0, 0, 0, 0, nullptr};
     return gemm(g, MODE_DENSE);
   }
   int conv(const float *in, const float *W, float *outp, int agents, int S, int Cin, int nchw) {
     const int So = (S - 3) / 2 + 1;
-    Gemm g{in, W, nullptr, outp, agents * So * So, HID, Cin * 9, 0, HID, S, Cin, So, 0};
+    Gemm g{in, W, nullptr, outp, agents * So * So, HID, Cin * 9, 0, HID, S, Cin, So, 0, 0, 0, nullptr};
     return gemm(g, nchw ? MODE_NCHW : MODE_NHWC);
   }
 };
@@ -567,6 +660,11 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
   SFP_HIP(hipSetDevice(device));
   Policy *p = new Policy();
   p->device = device, p->max_agents = max_agents;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      p->sk_blocks = 2 * prop.multiProcessorCount;
+  }
   int rc = SF_OK;
 #define SFP_TRY(x)   \
   if ((rc = (x))) {  \
@@ -626,6 +724,7 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
   SFP_TRY(p->dalloc(&p->x[0], B * HID));
   SFP_TRY(p->dalloc(&p->x[1], B * HID));
   SFP_TRY(p->dalloc(&p->lin, B * HID));
+  SFP_TRY(p->dalloc(&p->part, (size_t)p->sk_blocks * 2 * 128 * BN));
 #undef SFP_TRY
   *out = reinterpret_cast<sf_policy *>(p);
   return sf_policy_reset_memory(*out, nullptr);

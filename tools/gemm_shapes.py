@@ -9,8 +9,15 @@ pb = policy.PolicyBatch(policy.init_parameters(0), 4)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for name, M, N, K in [("conv0-shape", B * 225, 160, 288), ("conv1-shape", B * 49, 160, 1440), ("conv2-shape", B * 9, 160, 1440),
                       ("conv3-shape", B, 160, 1440), ("gru", B, 480, 160), ("lin", B, 160, 160)]:
-    a = torch.randn((M, K), device="cuda")
-    w = torch.randn((N, K), device="cuda")
+    if os.environ.get("GEMM_DATA") == "const":
+        a = torch.full((M, K), 0.5, device="cuda")
+        w = torch.full((N, K), 0.25, device="cuda")
+    elif os.environ.get("GEMM_DATA") == "zero":
+        a = torch.zeros((M, K), device="cuda")
+        w = torch.zeros((N, K), device="cuda")
+    else:
+        a = torch.randn((M, K), device="cuda")
+        w = torch.randn((N, K), device="cuda")
     c = torch.zeros((M, N), device="cuda")
     torch.cuda.synchronize()
     for _ in range(2):

@@ -5,10 +5,10 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int VARIANT>
-__global__ __launch_bounds__(256) void k(float *out, int iters) {
+__global__ __launch_bounds__(256) void k(float *out, int iters, int rnd) {
   __shared__ float lds[2][288 * 17];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  for (int i = t; i < 2 * 288 * 17; i += 256) (&lds[0][0])[i] = (float)(i & 7) * 0.125f;
+  for (int i = t; i < 2 * 288 * 17; i += 256) (&lds[0][0])[i] = rnd ? (float)((i * 2654435761u) >> 8) * (1.0f / 8388608.0f) - 1.0f : (float)(i & 7) * 0.125f;
   __syncthreads();
   f32x16 acc[5];
   for (int i = 0; i < 5; ++i)
@@ -36,24 +36,24 @@ __global__ __launch_bounds__(256) void k(float *out, int iters) {
 }
 
 template <int V>
-void run(const char *name, int blocks, size_t dyn) {
+void run(const char *name, int blocks, size_t dyn, int rnd = 0) {
   float *out;
-  hipMalloc(&out, (size_t)blocks * 256 * 4);
+  (void)hipMalloc(&out, (size_t)blocks * 256 * 4);
   const int iters = 2000;
-  if (dyn) hipFuncSetAttribute(reinterpret_cast<const void *>(k<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+  if (dyn) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
   hipEvent_t e0, e1;
-  hipEventCreate(&e0), hipEventCreate(&e1);
+  (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), dyn, 0, out, iters);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), dyn, 0, out, iters, rnd);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
     float ms;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     double flop = (double)blocks * 4 * iters * 40 * 4096.0;
     if (rep == 2) printf("%-28s blocks %5d dynLDS %6zu: %8.3f ms  %7.1f TFLOP/s\n", name, blocks, dyn, ms, flop / ms / 1e9);
   }
-  hipFree(out);
+  (void)hipFree(out);
 }
 
 int main() {
@@ -62,6 +62,9 @@ int main() {
     run<1>("mfma + lds reads", blocks, 0);
     run<2>("mfma + lds reads + barrier", blocks, 0);
   }
+  run<1>("random data: mfma + lds", 512, 0, 1);
+  run<2>("random data: + barrier", 512, 0, 1);
+  run<2>("random data: + barrier", 768, 0, 1);
   run<2>("1 block/CU (dyn lds)", 256, 90000);
   run<2>("1 block/CU x2 rounds", 512, 90000);
   return 0;
