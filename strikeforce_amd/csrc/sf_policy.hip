@@ -207,21 +207,25 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm(Gemm g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   };
-  // C/D map of the 32x32 tile: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+  // The products are issued transposed (W fragment as the MFMA's A operand, activation fragment as its B operand:
+  // the two operand lane maps are the same, so the fragments need no change), which puts the output row m on the
+  // lane (m = l&31) and four consecutive output columns n = 8*(reg>>2) + 4*(l>>5) + (reg&3) in consecutive
+  // registers: a tile leaves as 4 dwordx4 stores per lane instead of 16 dword stores.
   auto flush = [&](int tile, bool whole, int slot) {
-    const int m0 = tile * BM;
-    float *pt = g.part + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + slot) * (BM * BN);
+    const int ml = wm * 32 + (l & 31), m = tile * BM + ml;
+    float *pt = g.part + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + slot) * (BM * BN) + ml * BN;
+    float *cr = g.C + (size_t)m * g.ldc + n0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int nl = (wn * NT + nt) * 32 + (l & 31);
-      const float bv = (whole && g.bias) ? g.bias[n0 + nl] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      for (int q = 0; q < 4; ++q) {
+        const int nl = (wn * NT + nt) * 32 + 8 * q + 4 * (l >> 5);
+        f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
         if (whole) {
-          if (m0 + ml < g.M) g.C[(size_t)(m0 + ml) * g.ldc + n0 + nl] = acc[nt][r] + bv;
+          if (g.bias) v += ldg4(g.bias + n0 + nl);
+          if (m < g.M) *reinterpret_cast<f32x4 *>(cr + nl) = v;
         } else {
-          pt[ml * BN + nl] = acc[nt][r];
+          *reinterpret_cast<f32x4 *>(pt + nl) = v;
         }
       }
     }
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm(Gemm g) {
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[grp & 1][h], fb[grp & 1][nt][h], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[grp & 1][nt][h], fa[grp & 1][h], acc[nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (kt_c == KT - 1 || i == nu - 1) {
@@ -817,7 +821,7 @@ int sf_policy_gemm(sf_policy *pp, const float *d_a, int32_t lda, const float *d_
                    int32_t ldc, int32_t m, int32_t n, int32_t k) {
   Policy *p = reinterpret_cast<Policy *>(pp);
   if (!p || !d_a || !d_w || !d_c) return sfp::fail(SF_ERR_ARG, "null argument");
-  if (lda % 4 || lda < k || ldc < n) return sfp::fail(SF_ERR_ARG, "policy gemm: bad leading dimension");
+  if (lda % 4 || ldc % 4 || lda < k || ldc < n) return sfp::fail(SF_ERR_ARG, "policy gemm: bad leading dimension");
   SFP_HIP(hipSetDevice(p->device));
   return p->dense(d_a, lda, d_w, d_bias, d_c, ldc, m, n, k);
 }

@@ -9,7 +9,8 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LD
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_policy/f -- python3 tools/policy_bench.py 4096 4 > gpurun_out/pmc_policy/f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_policy/w -- python3 tools/policy_bench.py 4096 4 > gpurun_out/pmc_policy/w.log 2>&1
 python3 - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, json
+summary = {}
 for d in "abfw":
     fs = glob.glob("gpurun_out/pmc_policy/%s/*/*counter_collection.csv" % d)
     if not fs:
@@ -25,4 +26,6 @@ for d in "abfw":
     for k in acc:
         if "gemm" in k or "observe" in k:
             print(k, "dispatches", cnt[k], {c: v / cnt[k] for c, v in acc[k].items()})
+            summary.setdefault(k, {"dispatches": cnt[k]}).update({c: v / cnt[k] for c, v in acc[k].items()})
+json.dump(summary, open('gpurun_out/pmc_policy/summary.json', 'w'), indent=1)
 PY

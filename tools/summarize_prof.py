@@ -32,7 +32,7 @@ for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, tag + "_kernel_stats.csv"))
 for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
     rows = list(csv.DictReader(open(f)))
-    keep = [r for r in rows if "sf::" in r["Kernel_Name"]]
+    keep = [r for r in rows if "sf::" in r["Kernel_Name"] or "sfp::" in r["Kernel_Name"]]
     with open(os.path.join(dst, tag + "_kernel_trace_sf.csv"), "w", newline="") as out:
         w = csv.DictWriter(out, fieldnames=list(rows[0].keys()) + ["Duration_Ns"])
         w.writeheader()
