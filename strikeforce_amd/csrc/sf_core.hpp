@@ -117,26 +117,41 @@ struct Core {
   // game, so the table lookup for draw n+1 (the one long-latency link of the chain) is issued at the end of draw
   // n and waited for at the beginning of draw n+1; the logic in between runs under its latency.  `S.la` holds the
   // looked-up log; it is a pure function of the committed state (rl, jomle), so it is simply dropped at store time.
-  static SF_DEV void draw_issue(Arena &S, const Params &p) {  // first half of draw_core, up to the lookup
-    const P tap = W::ltu(W::lane(), 18u) & ((S.rl & RL_ZERO) == 0u);
-    const V pw = pow3_v(S.xt, (S.rl * S.rseed) & 0xffffu, tap);
-    V t = mod65537_v(W::sum18_row1(W::select(tap, S.rus * pw, V(0u))) + 1u);
+  //
+  // The hot-path form of the first half (draw_issue) differs from draw_core in three ways, all of them safe only on a
+  // warmed-up generator (no zero among random[0..17]: a new value is a power of a non-zero residue, so this holds from
+  // the 18th draw after _srand on, and draw() is only reached after the 1024 warm-up draws):
+  //   * no tap predicate: lanes >= 18 carry us = 0, so their term is 0 whatever their power is;
+  //   * lane 18 carries seed 1 and a copy of the newest log, so the same pair of LDS lookups that powers the 18
+  //     taps also yields 3^lnew = the value of the draw just made (its low 10 bits are rand()'s result, RN:61);
+  //   * the power is left as the signed difference lo16 - hi16 of the table product (congruent mod 65537, magnitude
+  //     < 2^16); the terms are summed signed and one constant multiple of 65537 makes the total positive before the
+  //     single reduction of the sum.
+  static constexpr uint32_t SUM_BIAS = 1u + 181u * 65537u;  // 18 * 10 * 65535 < 181 * 65537
+  static SF_DEV uint32_t draw_issue(Arena &S, const Params &p) {
+    const V m = W::mul24(S.rl, S.rseed) & 0xffffu;
+    const V pr = W::mul24(W::lds_u32(S.xt, m & 255u, W::all()), W::lds_u32(S.xt + 256, m >> 8, W::all()));
+    const V d = (pr & 0xffffu) - (pr >> 16);  // == 3^m (mod 65537), in (-65536, 65536)
+    V t = mod65537_v(W::sum18_row1(S.rus * d) + SUM_BIAS);
     t = W::select(t == 0u, V(1u), t);
     S.la = W::gload_u16(p.logt, (t - 1u) & 65535u, W::all());
     S.la_ok = 1u;
+    const int32_t o = (int32_t)W::readlane(d, 18u);
+    return (uint32_t)(o + ((o >> 31) & 65537)) & 1023u;
   }
   static SF_DEV uint32_t draw(Arena &S, const uint8_t *, const Params &p) {  // RN:54-62
     if (!S.la_ok) draw_issue(S, p);
     S.draws += 1u;
     S.jomle += 1u;
-    const V lnew = (S.la * (S.jomle & 0xffffu)) & 0xffffu;
-    S.rl = W::select(W::lane() == 17u, lnew, W::shl1(S.rl));
-    draw_issue(S, p);  // draw n+1's lookup is now in flight
-    return W::readlane(pow3_v(S.xt, lnew, W::all()) & 1023u, 17u);
+    const V lnew = W::mul24(S.la, V(S.jomle & 0xffffu)) & 0xffffu;
+    const V ln = W::lane();
+    S.rl = W::select((ln == 17u) | (ln == 18u), lnew, W::shl1(S.rl));  // rotate left, new value last (+ copy on 18)
+    return draw_issue(S, p);  // draw n+1's lookup is now in flight; lane 18's power is draw n's value
   }
 
-  static SF_DEV void seed_digits(V &digits, uint64_t x) {  // RN:65-68: decimal digit i of x, plus one, on lane i
+  static SF_DEV void seed_digits(V &digits, uint64_t x, uint32_t lane18 = 0u) {  // RN:65-68: decimal digit i of x, plus one, on lane i
     digits = V(0u);
+    W::setlane(digits, 18u, lane18);  // seeds: 1 (draw_issue's output lane); us: 0
     for (int i = 0; i < 18; ++i) {
       W::setlane(digits, (uint32_t)i, (uint32_t)(x % 10u) + 1u);
       x /= 10u;
@@ -146,7 +161,7 @@ struct Core {
     S.rl = V(RL_ZERO);
     S.la_ok = 0u;
     seed_digits(S.rus, us);
-    seed_digits(S.rseed, tb);
+    seed_digits(S.rseed, tb, 1u);
     S.jomle = 18u;
     (void)lds;
     for (int i = 0; i < 1024; ++i) draw_core<false>(S.rl, S.rus, S.rseed, S.jomle, S.xt, p);
@@ -957,7 +972,7 @@ struct Core {
       srand_(S, lds, p, tb, serial);
     }
     if (p.auto_reset) {  // arm the warm-up of the episode after this one
-      seed_digits(S.rseed2, tb + (uint64_t)(uint32_t)p.reseed);
+      seed_digits(S.rseed2, tb + (uint64_t)(uint32_t)p.reseed, 1u);
       S.rl2 = V(RL_ZERO);
       S.warm = 0u;
     }
@@ -1067,11 +1082,11 @@ struct Core {
       const P in = W::ltu(ln, 18u);
       const V rw = W::gload(p.rng + (size_t)a * RNG_WORDS, ln, in);
       const V val = rw & 0xfffffu;
-      S.rus = (rw >> 20) & 15u, S.rseed = (rw >> 24) & 15u;
+      S.rus = (rw >> 20) & 15u, S.rseed = W::select(ln == 18u, V(1u), (rw >> 24) & 15u);
       const P nz = in & (val != 0u);
       S.rl = W::select(nz, W::gload_u16(p.logt, val - 1u, nz), V(RL_ZERO));
       const V rw2 = W::gload(p.rng2 + (size_t)a * RNG_WORDS, ln, in);  // log form: never dumped
-      S.rl2 = rw2 & 0x1ffffu, S.rseed2 = rw2 >> 24;
+      S.rl2 = rw2 & 0x1ffffu, S.rseed2 = W::select(ln == 18u, V(1u), rw2 >> 24);
     }
     const V sc = W::gload((const uint32_t *)p.scal + (size_t)a * SC_WORDS, ln, W::ltu(ln, (uint32_t)SC_WORDS));
     S.frame = (int32_t)W::readlane(sc, SC_FRAME), S.kills = (int32_t)W::readlane(sc, SC_KILLS);

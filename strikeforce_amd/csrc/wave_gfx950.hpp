@@ -69,6 +69,8 @@ struct WaveGfx950 {
     return (uint32_t)x;
   }
   static SF_DEV V minu(V a, V b) { return a < b ? a : b; }
+  // low 32 bits of a product whose operands are below 2^24 (v_mul_u32_u24)
+  static SF_DEV V mul24(V a, V b) { return __umul24(a, b); }
   // lane i <- lane i + 1 (wave_shl:1, a gfx9 DPP control); lane 63 reads 0
   static SF_DEV V shl1(V v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 

@@ -129,6 +129,11 @@ struct WaveEmu {
     for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i];
     return r;
   }
+  static V mul24(const V &a, const V &b) {  // operands below 2^24, like v_mul_u32_u24
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = (a.v[i] & 0xffffffu) * (b.v[i] & 0xffffffu);
+    return r;
+  }
   static V shl1(const V &a) {
     V r;
     for (int i = 0; i < 63; ++i) r.v[i] = a.v[i + 1];
