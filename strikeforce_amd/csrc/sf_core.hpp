@@ -43,6 +43,7 @@ struct Core {
     V ppos;
     // RNG (lane < 18): log_3(random[i]) (bit 16 set: random[i] == 0), us[i], seed[i]  RN:31
     V rl, rus, rseed;
+    V rs4;  // 4 * rseed: the draw's exponent comes out pre-scaled to a byte offset into the power table
     // the NEXT episode's generator, warmed up a few draws per step so that an in-kernel restart does not stall on
     // _srand's 1024 serial draws (RN:73-74): log state, seed digits, draws done so far (0..1024)
     V rl2, rseed2;
@@ -52,6 +53,9 @@ struct Core {
     // one-deep lookahead of draw(): the log looked up for the next draw, and whether it is valid
     V la;
     uint32_t la_ok;
+    // the same for the next episode's generator (prewarm_one)
+    V la2;
+    uint32_t la2_ok;
     // wave-uniform scalars  G:461
     int32_t frame, kills, tkills, loot, chests, steps, episodes, done, outcome, ended;
     uint32_t jomle, draws;
@@ -107,7 +111,7 @@ struct Core {
     jomle += 1u;
     const uint32_t e = jomle & 0xffffu;  // b %= mod - 1
     // (& 65535: lanes outside 16..31 hold junk and must still read inside the table)
-    const V lg = W::gload_u16(p.logt, (t - 1u) & 65535u, W::all());
+    const V lg = W::gload_u16(p.logt, t + (uint32_t)LOGT_OFF, W::all());  // t <= 65536 whatever a junk lane summed
     const V lnew = (lg * e) & 0xffffu;
     rl = W::select(W::lane() == 17u, lnew, W::shl1(rl));  // the 17 swaps: rotate left, new value last
     if (WANT_OUT) return pow3_v(xt, lnew, W::all()) & 1023u;
@@ -129,17 +133,20 @@ struct Core {
   //     single reduction of the sum.
   static constexpr uint32_t SUM_BIAS = 1u + 181u * 65537u;  // 18 * 10 * 65535 < 181 * 65537
   static SF_DEV uint32_t draw_issue(Arena &S, const Params &p) {
-    const V m = W::mul24(S.rl, S.rseed) & 0xffffu;
-    const V pr = W::mul24(W::lds_u32(S.xt, m & 255u, W::all()), W::lds_u32(S.xt + 256, m >> 8, W::all()));
+    const V m4 = W::mul24(S.rl, S.rs4);  // 4 * (log * seed); bits above 4 * 65536 are multiples of the group order
+    const V pr = W::mul24(W::lds_u32_at(S.xt, m4 & 0x3fcu), W::lds_u32_at(S.xt + 256, (m4 >> 8) & 0x3fcu));
     const V d = (pr & 0xffffu) - (pr >> 16);  // == 3^m (mod 65537), in (-65536, 65536)
-    V t = mod65537_v(W::sum18_row1(S.rus * d) + SUM_BIAS);
-    t = W::select(t == 0u, V(1u), t);
-    S.la = W::gload_u16(p.logt, (t - 1u) & 65535u, W::all());
+    const V x = W::sum18_row1(S.rus * d) + SUM_BIAS;  // < 2^25 on lanes 16..31
+    const V t = (x & 0xffffu) - (x >> 16);             // == x (mod 65537), in (-512, 65536): the table does the rest
+    // every lane holds a row sum of zero-or-tap terms plus the bias (rows 0, 2, 3 just their own), so every index is
+    // inside the table
+    S.la = W::gload_u16(p.logt, t + (uint32_t)LOGT_OFF, W::all());
     S.la_ok = 1u;
     const int32_t o = (int32_t)W::readlane(d, 18u);
     return (uint32_t)(o + ((o >> 31) & 65537)) & 1023u;
   }
   static SF_DEV uint32_t draw(Arena &S, const uint8_t *, const Params &p) {  // RN:54-62
+    SF_PROF(PH_RNG);
     if (!S.la_ok) draw_issue(S, p);
     S.draws += 1u;
     S.jomle += 1u;
@@ -162,15 +169,43 @@ struct Core {
     S.la_ok = 0u;
     seed_digits(S.rus, us);
     seed_digits(S.rseed, tb, 1u);
+    S.rs4 = S.rseed << 2;
     S.jomle = 18u;
     (void)lds;
     for (int i = 0; i < 1024; ++i) draw_core<false>(S.rl, S.rus, S.rseed, S.jomle, S.xt, p);
   }
   // advance the next episode's warm-up by up to n draws
-  static SF_DEV void prewarm(Arena &S, const uint8_t *lds, const Params &p, uint32_t n) {
+  // One warm-up draw of the NEXT episode's generator.  Past its first 18 draws (no zero left in the state) it runs in
+  // the same lean, split form as draw(): commit the draw whose log lookup was issued by the previous call, issue the
+  // next one, so that the lookup's latency passes under whatever runs between two calls.  `S.la2` is a pure function
+  // of (rl2, warm) and is dropped at store time like `S.la`.
+  static SF_DEV void prewarm_issue(Arena &S, const Params &p) {
+    const V m4 = W::mul24(S.rl2, S.rseed2) << 2;
+    const V pr = W::mul24(W::lds_u32_at(S.xt, m4 & 0x3fcu), W::lds_u32_at(S.xt + 256, (m4 >> 8) & 0x3fcu));
+    const V d = (pr & 0xffffu) - (pr >> 16);
+    const V x = W::sum18_row1(S.rus * d) + SUM_BIAS;
+    const V t = (x & 0xffffu) - (x >> 16);
+    S.la2 = W::gload_u16(p.logt, t + (uint32_t)LOGT_OFF, W::all());
+    S.la2_ok = 1u;
+  }
+  static SF_DEV void prewarm_one(Arena &S, const Params &p) {
+    SF_PROF(PH_WARM);
+    if (S.warm >= 1024u) return;
     uint32_t j2 = 18u + S.warm;
+    if (S.warm < 18u) {
+      draw_core<false>(S.rl2, S.rus, S.rseed2, j2, S.xt, p);
+    } else {
+      if (!S.la2_ok) prewarm_issue(S, p);
+      const V lnew = W::mul24(S.la2, V((j2 + 1u) & 0xffffu)) & 0xffffu;
+      S.rl2 = W::select(W::lane() == 17u, lnew, W::shl1(S.rl2));
+      S.la2_ok = 0u;
+      if (S.warm + 1u < 1024u) prewarm_issue(S, p);
+    }
+    ++S.warm;
+  }
+  static SF_DEV void prewarm(Arena &S, const uint8_t *lds, const Params &p, uint32_t n) {
     (void)lds;
-    for (; n && S.warm < 1024u; --n, ++S.warm) draw_core<false>(S.rl2, S.rus, S.rseed2, j2, S.xt, p);
+    for (; n && S.warm < 1024u; --n) prewarm_one(S, p);
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -383,6 +418,7 @@ struct Core {
   // so everything except "is another zombie there now" is computed once, lane-parallel, one lane per zombie, and
   // the slot-ordered loop that fixes the RNG draw order only tests bits, draws, and asks one ballot per move.
   static SF_DEV void zombie_action(Arena &S, uint8_t *lds, const Params &p) {
+    SF_PROF(PH_ZOMBIE);
     const P zalive = ((S.zpos & ZF_ALIVE) != 0u) & W::ltu(W::lane(), (uint32_t)p.Z);
     uint64_t zm = W::ballot(zalive);
     if (!zm) return;
@@ -466,6 +502,7 @@ struct Core {
   // ------------------------------------------------------------------------------------------------
   // portal_damage G:1279-1297
   static SF_DEV void portal_damage(Arena &S, uint8_t *lds, const Params &p) {
+    SF_PROF(PH_PORTAL);
     uint64_t pm = W::ballot((S.ppos & PF_ACTIVE) != 0u) & capmask(p.P);
     while (pm) {
       const uint32_t i = (uint32_t)W::ctz64(pm);
@@ -508,6 +545,7 @@ struct Core {
   }
 
   static SF_DEV void update_tmp(Arena &S, uint8_t *lds, const Params &p, int a) {
+    SF_PROF(PH_TMP);
     uint64_t cand[NB];
     V cell[NB];
     bool any = false;
@@ -560,6 +598,7 @@ struct Core {
   // (lane-parallel); (2) one wave-uniform pass over designated bullets that share a cell with a live
   // character.  All cross-entity effects are additive (owner damage/effect/kills, loot, kill counters).
   static SF_DEV void hits(Arena &S, const Params &p) {
+    SF_PROF(PH_HITS);
     {
       const P dying = ((S.hfl & HF_ALIVE) != 0u) & W::le0(S.hhp);                  // G:641-645
       // s[0] = (human == &hum[ind]); deleteAgent() only for i != ind  G:643,648-649
@@ -629,6 +668,7 @@ struct Core {
   // update_bull G:1059-1100.  Expiry / advance is lane-parallel; "the last bullet to enter a cell becomes
   // the cell's designated bullet" is resolved per distinct destination with ballots.
   static SF_DEV void update_bull(Arena &S, uint8_t *lds, const Params &p) {
+    SF_PROF(PH_BULL);
     bool any = false;
 #pragma unroll
     for (int j = 0; j < NB; ++j) any = any || W::ballot((S.ba[j] & BA_ALIVE) != 0u) != 0ull;
@@ -878,6 +918,7 @@ struct Core {
 
   // human_action G:965-1012.  S.hcmd holds this step's external commands on lanes < n_agents.
   static SF_DEV void human_action(Arena &S, uint8_t *lds, const Params &p, int a) {
+    SF_PROF(PH_HUMAN);
     const uint64_t alive = W::ballot((S.hfl & HF_ALIVE) != 0u) & capmask(p.H);
     // get_command G:929-937, slot order, for i != ind: remote keep theirs, rnpc draw, agents keep theirs, others '+'
     {
@@ -939,6 +980,7 @@ struct Core {
 
   // top of play()'s while(true): G:1444-1450
   static SF_DEV void loop_top(Arena &S, uint8_t *lds, const Params &p, int a) {
+    SF_PROF(PH_TOP);
     spawns(S, lds, p);
     const int out = check_end(S, p);
     if (out != SF_RUNNING) {
@@ -966,7 +1008,7 @@ struct Core {
     S.dirty = 1u;
     if (adopt) {
       prewarm(S, lds, p, 1024u);  // whatever is still missing
-      S.rl = S.rl2, S.rseed = S.rseed2, S.jomle = 18u + 1024u;
+      S.rl = S.rl2, S.rseed = S.rseed2, S.rs4 = S.rseed2 << 2, S.jomle = 18u + 1024u;
       S.la_ok = 0u;
     } else {
       srand_(S, lds, p, tb, serial);
@@ -974,7 +1016,7 @@ struct Core {
     if (p.auto_reset) {  // arm the warm-up of the episode after this one
       seed_digits(S.rseed2, tb + (uint64_t)(uint32_t)p.reseed, 1u);
       S.rl2 = V(RL_ZERO);
-      S.warm = 0u;
+      S.warm = 0u, S.la2_ok = 0u;
     }
     // load_data(): who stands where.  Solo/Timer: the player at (0,1,1) (G:1905-1920).  Squad: the player at (0,3,1),
     // four team-mates at (0,1,2..5), five opponents at (squad_floor,1,6..10), all built from the NPC record
@@ -1022,13 +1064,14 @@ struct Core {
       } else {
         human_action(S, lds, p, a);
       }
-      update_tmp(S, lds, p, a);
+      if (p.auto_reset) prewarm_one(S, p);  // four warm-up draws of the next episode per step, spread out so that
+      update_tmp(S, lds, p, a);             // each one's table lookup is in flight while the tick goes on
       hits(S, p);
       ++S.frame;  // updmap G:489-495 clears render-only bits
+      if (p.auto_reset) prewarm_one(S, p);
       update_bull(S, lds, p);
     }
     ++S.steps;
-    if (p.auto_reset) prewarm(S, lds, p, 4u);
     // the loop top; when the episode ends and auto_reset is on, once more for the episode that begins
     SF_NOUNROLL for (int pass = 0; pass < 2; ++pass) {
       loop_top(S, lds, p, a);
@@ -1083,8 +1126,9 @@ struct Core {
       const V rw = W::gload(p.rng + (size_t)a * RNG_WORDS, ln, in);
       const V val = rw & 0xfffffu;
       S.rus = (rw >> 20) & 15u, S.rseed = W::select(ln == 18u, V(1u), (rw >> 24) & 15u);
+      S.rs4 = S.rseed << 2;
       const P nz = in & (val != 0u);
-      S.rl = W::select(nz, W::gload_u16(p.logt, val - 1u, nz), V(RL_ZERO));
+      S.rl = W::select(nz, W::gload_u16(p.logt, val + (uint32_t)LOGT_OFF, nz), V(RL_ZERO));
       const V rw2 = W::gload(p.rng2 + (size_t)a * RNG_WORDS, ln, in);  // log form: never dumped
       S.rl2 = rw2 & 0x1ffffu, S.rseed2 = W::select(ln == 18u, V(1u), rw2 >> 24);
     }
@@ -1155,14 +1199,16 @@ struct Core {
 
   // ------------------------------------------------------------------------------------------------
   // kernel bodies
-  // LDS layout of a workgroup (= one wavefront = one arena): [flag plane : cells_pad][power table : 2 KiB];
-  // with HBM_PLANE only the power table, and `lds` (the plane) is the arena's slice of Params::flags
+  // LDS layout of a workgroup (= one wavefront = one arena): [power table : 2 KiB][flag plane : cells_pad] (the table
+  // first, so that its address is a compile-time DS offset); with HBM_PLANE only the power table, and `lds` (the
+  // plane) is the arena's slice of Params::flags
   static SF_DEV uint8_t *tables(Arena &S, uint8_t *lds, const Params &p, int a) {
-    uint8_t *tab = HBM_PLANE ? lds : lds + p.cells_pad;
+    uint8_t *tab = lds;
     W::copy_g2l(tab, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
     S.xt = reinterpret_cast<const uint32_t *>(tab);
     S.la = V(0u), S.la_ok = 0u;
-    return HBM_PLANE ? p.flags + (size_t)a * (size_t)p.cells_pad : lds;
+    S.la2 = V(0u), S.la2_ok = 0u;
+    return HBM_PLANE ? p.flags + (size_t)a * (size_t)p.cells_pad : lds + LDS_TABLE_BYTES;
   }
 
   static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial) {

@@ -247,12 +247,13 @@ struct Env {
     }
     cfg.map = nullptr, cfg.map_portal = nullptr;  // the caller's buffers are not kept
     // RNG tables: discrete logs / powers of the generator 3 of Z/65537*
-    std::vector<uint16_t> logt(65536);
+    std::vector<uint16_t> logt(LOGT_ENTRIES, 0);
     std::vector<uint32_t> exptab(512);
     {
       uint32_t v = 1;
       for (uint32_t m = 0; m < 65536; ++m) {
-        logt[v - 1] = (uint16_t)m;
+        logt[LOGT_OFF + v] = (uint16_t)m;                                              // t = v
+        if (v + (uint32_t)LOGT_OFF >= 65537u) logt[LOGT_OFF + v - 65537u] = (uint16_t)m;  // t = v - 65537 < 0
         if (m < 256) exptab[m] = v;
         if ((m & 255u) == 0) exptab[256 + (m >> 8)] = v;
         v = (uint32_t)(((uint64_t)v * 3u) % 65537u);
@@ -260,7 +261,7 @@ struct Env {
     }
     // device state
     const size_t A = (size_t)p.A;
-    if ((rc = alloc(d_logt, 65536)) || (rc = alloc(d_exptab, 512)) || (rc = alloc(d_tab, 1)) || (rc = alloc(d_map_flags, (size_t)p.cells_pad)) || (rc = alloc(d_map_pidx, (size_t)cells)) ||
+    if ((rc = alloc(d_logt, (size_t)LOGT_ENTRIES)) || (rc = alloc(d_exptab, 512)) || (rc = alloc(d_tab, 1)) || (rc = alloc(d_map_flags, (size_t)p.cells_pad)) || (rc = alloc(d_map_pidx, (size_t)cells)) ||
         (rc = alloc(d_map_exits, (size_t)p.P)) || (rc = alloc(p.hum, HW_WORDS * A * p.H)) ||
         (rc = alloc(p.zom, ZW_WORDS * A * p.Z)) || (rc = alloc(p.bul, BW_WORDS * A * p.B)) ||
         (rc = alloc(p.por, A * p.P)) || (rc = alloc(p.rng, A * RNG_WORDS)) || (rc = alloc(p.rng2, A * RNG_WORDS)) || (rc = alloc(p.scal, A * SC_WORDS)) ||

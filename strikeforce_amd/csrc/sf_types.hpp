@@ -101,9 +101,16 @@ struct Params {
   const uint8_t *map_flags;  // [cells_pad]
   const int16_t *map_pidx;   // [cells]
   const uint32_t *map_exits; // [P]
-  const uint16_t *logt;      // [65536] log_3(v) for v = 1..65536 at index v-1 (RNG, sf_core.hpp draw())
+  const uint16_t *logt;      // [LOGT_OFF + 65537] log_3 of the residue (j - LOGT_OFF) mod 65537 at index j, 0 for residue 0
+                             // (RNG, sf_core.hpp draw())
   const uint32_t *exptab;    // [512] 3^i (i < 256) then 3^(256 i): staged in LDS behind the flag plane
 };
+
+// The log table is indexed by the half-reduced tap sum t = lo16(x) - hi16(x), x < 2^25, i.e. t in (-512, 65536):
+// entry t + LOGT_OFF holds log_3(t mod 65537), and the entry of residue 0 holds log_3(1) = 0, which is RN:58's
+// `sum + (int)(sum == 0)`.  A value v in [1, 65536] is looked up at v + LOGT_OFF.
+constexpr int LOGT_OFF = 512;
+constexpr int LOGT_ENTRIES = LOGT_OFF + 65537;
 
 inline int nb_for(int B) { return (B + 63) / 64; }
 constexpr int LDS_TABLE_BYTES = 2048;  // exptab

@@ -27,6 +27,8 @@ static __device__ __forceinline__ SF_GLOBAL T *gptr(T *p) {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // 16 B per lane; a builtin vector, usable in any address space
 
+#define SF_PROF(ph)  // phase markers of the CPU emulator's op profile (tests/emu/wave_emu.hpp): nothing on the device
+
 struct WaveGfx950 {
   using V = uint32_t;
   using P = bool;
@@ -79,6 +81,10 @@ struct WaveGfx950 {
   static SF_DEV uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return uni((uint32_t)lds[idx]); }
   static SF_DEV V lds_u32(const uint32_t *lds, V idx, P pred) { return pred ? lds[idx] : 0u; }
   static SF_DEV uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return uni(lds[idx]); }
+  // 32-bit LDS word at a byte offset (a multiple of 4), every lane
+  static SF_DEV V lds_u32_at(const uint32_t *lds, V byte_off) {
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lds) + byte_off);
+  }
   static SF_DEV void ulds_store_u8(uint8_t *lds, uint32_t idx, uint32_t val) {
     lds[idx] = (uint8_t)val;  // every lane writes the same byte: no divergence, one LDS pass
     __builtin_amdgcn_wave_barrier();

@@ -129,6 +129,15 @@ struct sfe_env {
 };
 
 extern "C" {
+// op profile of the device source: out[0] = all vector ops, out[1 + ph] = ops in phase ph; clears the counters
+int sfe_profile(uint64_t *out) {
+  sf::EmuProf &q = sf::emu_prof();
+  q.by[q.phase] += q.ops - q.mark, q.mark = q.ops;
+  out[0] = q.ops;
+  for (int i = 0; i < sf::PH_COUNT; ++i) out[1 + i] = q.by[i], q.by[i] = 0;
+  q.ops = q.mark = 0;
+  return sf::PH_COUNT;
+}
 sfe_env *sfe_create(const sf_config *cfg) {
   sfe_env *env = new sfe_env();
   if (env->e.create(cfg) != SF_OK) {

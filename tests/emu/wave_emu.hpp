@@ -12,6 +12,33 @@
 
 namespace sf {
 
+// Vector-op profile of the device source (one count per emulated 64-lane operation), by phase of the tick: a
+// stand-in for per-phase VALU instruction counts, used to decide where the kernel's issue slots go.
+enum { PH_OTHER, PH_RNG, PH_ZOMBIE, PH_PORTAL, PH_HUMAN, PH_TMP, PH_HITS, PH_BULL, PH_TOP, PH_WARM, PH_COUNT };
+struct EmuProf {
+  uint64_t ops = 0, mark = 0, by[PH_COUNT] = {};
+  int phase = PH_OTHER;
+};
+inline EmuProf &emu_prof() {
+  static EmuProf p;
+  return p;
+}
+struct EmuProfScope {
+  int prev;
+  explicit EmuProfScope(int ph) {
+    EmuProf &q = emu_prof();
+    q.by[q.phase] += q.ops - q.mark, q.mark = q.ops;
+    prev = q.phase, q.phase = ph;
+  }
+  ~EmuProfScope() {
+    EmuProf &q = emu_prof();
+    q.by[q.phase] += q.ops - q.mark, q.mark = q.ops;
+    q.phase = prev;
+  }
+};
+#define SF_PROF(ph) ::sf::EmuProfScope sf_prof_scope_(::sf::ph)
+#define EMU_OP() (++::sf::emu_prof().ops)
+
 struct EmuP {
   uint64_t m;
 };
@@ -28,12 +55,12 @@ struct EmuV {
 };
 #define EMU_BIN(op)                                              \
   inline EmuV operator op(const EmuV &a, const EmuV &b) {        \
-    EmuV r;                                                      \
+    EMU_OP(); EmuV r;                                            \
     for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] op b.v[i];      \
     return r;                                                    \
   }                                                              \
   inline EmuV operator op(const EmuV &a, uint32_t b) {           \
-    EmuV r;                                                      \
+    EMU_OP(); EmuV r;                                            \
     for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] op b;           \
     return r;                                                    \
   }
@@ -45,28 +72,31 @@ EMU_BIN(|)
 EMU_BIN(^)
 #undef EMU_BIN
 inline EmuV operator<<(const EmuV &a, int s) {
+  EMU_OP();
   EmuV r;
   for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] << s;
   return r;
 }
 inline EmuV operator>>(const EmuV &a, int s) {
+  EMU_OP();
   EmuV r;
   for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] >> s;
   return r;
 }
 inline EmuV operator~(const EmuV &a) {
+  EMU_OP();
   EmuV r;
   for (int i = 0; i < 64; ++i) r.v[i] = ~a.v[i];
   return r;
 }
 #define EMU_CMP(op)                                                                \
   inline EmuP operator op(const EmuV &a, const EmuV &b) {                          \
-    EmuP r{0};                                                                     \
+    EMU_OP(); EmuP r{0};                                                           \
     for (int i = 0; i < 64; ++i) r.m |= (uint64_t)(a.v[i] op b.v[i]) << i;         \
     return r;                                                                      \
   }                                                                                \
   inline EmuP operator op(const EmuV &a, uint32_t b) {                             \
-    EmuP r{0};                                                                     \
+    EMU_OP(); EmuP r{0};                                                           \
     for (int i = 0; i < 64; ++i) r.m |= (uint64_t)(a.v[i] op b) << i;              \
     return r;                                                                      \
   }
@@ -79,6 +109,7 @@ struct WaveEmu {
   using P = EmuP;
 
   static V lane() {
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = (uint32_t)i;
     return r;
@@ -89,26 +120,31 @@ struct WaveEmu {
   static uint32_t readlane(const V &v, uint32_t idx) { return v.v[idx & 63u]; }
   static void setlane(V &v, uint32_t idx, uint32_t val) { v.v[idx & 63u] = val; }
   static V select(P p, const V &a, const V &b) {
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = ((p.m >> i) & 1ull) ? a.v[i] : b.v[i];
     return r;
   }
   static V sar31(const V &a) {
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = (uint32_t)((int32_t)a.v[i] >> 31);
     return r;
   }
   static P le0(const V &a) {
+    EMU_OP();
     P r{0};
     for (int i = 0; i < 64; ++i) r.m |= (uint64_t)((int32_t)a.v[i] <= 0) << i;
     return r;
   }
   static P ltu(const V &a, const V &b) {
+    EMU_OP();
     P r{0};
     for (int i = 0; i < 64; ++i) r.m |= (uint64_t)(a.v[i] < b.v[i]) << i;
     return r;
   }
   static P ltu(const V &a, uint32_t b) {
+    EMU_OP();
     P r{0};
     for (int i = 0; i < 64; ++i) r.m |= (uint64_t)(a.v[i] < b) << i;
     return r;
@@ -117,47 +153,61 @@ struct WaveEmu {
   static P all() { return P{~0ull}; }
   static V vec(uint32_t x) { return V(x); }
   static uint32_t first(const V &v) { return v.v[0]; }
-  static V sum18_row1(const V &a) {  // like the DPP version: meaningful on lanes 16..31 only
-    uint32_t r0 = 0, r1 = 0;
-    for (int i = 0; i < 16; ++i) r0 += a.v[i], r1 += a.v[16 + i];
+  static V sum18_row1(const V &a) {  // like the DPP version: every lane gets its 16-lane row's sum, row 1 also row 0's
+    uint32_t rs[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 64; ++i) rs[i >> 4] += a.v[i];
+    EMU_OP();
     V r;
-    for (int i = 0; i < 64; ++i) r.v[i] = i < 16 ? r0 : (i < 32 ? r0 + r1 : 0xdeadbeefu);
+    for (int i = 0; i < 64; ++i) r.v[i] = rs[i >> 4] + ((i >> 4) == 1 ? rs[0] : 0u);
     return r;
   }
   static V minu(const V &a, const V &b) {
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i];
     return r;
   }
   static V mul24(const V &a, const V &b) {  // operands below 2^24, like v_mul_u32_u24
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = (a.v[i] & 0xffffffu) * (b.v[i] & 0xffffffu);
     return r;
   }
   static V shl1(const V &a) {
+    EMU_OP();
     V r;
     for (int i = 0; i < 63; ++i) r.v[i] = a.v[i + 1];
     r.v[63] = 0;
     return r;
   }
   static V lds_u8(const uint8_t *lds, const V &idx, P pred) {
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
     return r;
   }
   static uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return lds[idx]; }
   static V lds_u32(const uint32_t *lds, const V &idx, P pred) {
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
     return r;
   }
   static uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return lds[idx]; }
+  static V lds_u32_at(const uint32_t *lds, const V &byte_off) {
+    EMU_OP();
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = lds[byte_off.v[i] >> 2];
+    return r;
+  }
   static V lds_u16(const uint16_t *lds, const V &idx, P pred) {
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
     return r;
   }
   static V gload_u16(const uint16_t *base, const V &idx, P pred) {
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? base[idx.v[i]] : 0u;
     return r;
@@ -168,11 +218,13 @@ struct WaveEmu {
   static int32_t uload_i16(const int16_t *p) { return *p; }
   static void ustore_i16(int16_t *p, int16_t v) { *p = v; }
   static V gload(const uint32_t *base, const V &idx, P pred) {
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? base[idx.v[i]] : 0u;
     return r;
   }
   static V gload_u8(const uint8_t *base, const V &idx, P pred) {
+    EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? base[idx.v[i]] : 0u;
     return r;
