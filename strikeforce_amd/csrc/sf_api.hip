@@ -24,13 +24,13 @@ namespace sf {
 // HP (HBM_PLANE): maps whose flag plane is too large for LDS keep it in HBM (sf_core.hpp); dynamic LDS = power table only
 template <int NB, bool HP>
 __global__ __launch_bounds__(64) void k_reset(Params p, const uint64_t *tb, const uint64_t *serial) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  extern __shared__ __attribute__((aligned(2048))) uint8_t lds[];  // the RNG power table comes first (W::pow_pair)
   Core<WaveGfx950, NB, HP>::reset_body(lds, p, (int)blockIdx.x, tb, serial);
 }
 
 template <int NB, bool HP>
 __global__ __launch_bounds__(64) void k_step(Params p, const uint8_t *cmds, int k) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  extern __shared__ __attribute__((aligned(2048))) uint8_t lds[];  // the RNG power table comes first (W::pow_pair)
   Core<WaveGfx950, NB, HP>::step_body(lds, p, (int)blockIdx.x, cmds, k);
 }
 

@@ -51,14 +51,13 @@ struct Core {
     // RNG power table in LDS: 3^i (i < 256), then 3^(256 i)
     const uint32_t *xt;
     // one-deep lookahead of draw(): the log looked up for the next draw, and whether it is valid
-    V la;
-    uint32_t la_ok;
+    V la;  // valid whenever draw() can run: (re)issued by load(), srand_(), the adoption of a warmed-up generator, draw()
     // the same for the next episode's generator (prewarm_one)
     V la2;
     uint32_t la2_ok;
     // wave-uniform scalars  G:461
     int32_t frame, kills, tkills, loot, chests, steps, episodes, done, outcome, ended;
-    uint32_t jomle, draws;
+    uint32_t jomle;
     uint32_t tb_lo, tb_hi, sr_lo, sr_hi;
     uint32_t dirty;  // the LDS flag plane differs from HBM
   };
@@ -134,21 +133,18 @@ struct Core {
   static constexpr uint32_t SUM_BIAS = 1u + 181u * 65537u;  // 18 * 10 * 65535 < 181 * 65537
   static SF_DEV uint32_t draw_issue(Arena &S, const Params &p) {
     const V m4 = W::mul24(S.rl, S.rs4);  // 4 * (log * seed); bits above 4 * 65536 are multiples of the group order
-    const V pr = W::mul24(W::lds_u32_at(S.xt, m4 & 0x3fcu), W::lds_u32_at(S.xt + 256, (m4 >> 8) & 0x3fcu));
+    const V pr = W::pow_pair(S.xt, m4);
     const V d = (pr & 0xffffu) - (pr >> 16);  // == 3^m (mod 65537), in (-65536, 65536)
     const V x = W::sum18_row1(S.rus * d) + SUM_BIAS;  // < 2^25 on lanes 16..31
     const V t = (x & 0xffffu) - (x >> 16);             // == x (mod 65537), in (-512, 65536): the table does the rest
     // every lane holds a row sum of zero-or-tap terms plus the bias (rows 0, 2, 3 just their own), so every index is
     // inside the table
-    S.la = W::gload_u16(p.logt, t + (uint32_t)LOGT_OFF, W::all());
-    S.la_ok = 1u;
+    S.la = W::gload_u16_at(p.logt, (t << 1) + 2u * (uint32_t)LOGT_OFF);
     const int32_t o = (int32_t)W::readlane(d, 18u);
     return (uint32_t)(o + ((o >> 31) & 65537)) & 1023u;
   }
   static SF_DEV uint32_t draw(Arena &S, const uint8_t *, const Params &p) {  // RN:54-62
     SF_PROF(PH_RNG);
-    if (!S.la_ok) draw_issue(S, p);
-    S.draws += 1u;
     S.jomle += 1u;
     const V lnew = W::mul24(S.la, V(S.jomle & 0xffffu)) & 0xffffu;
     const V ln = W::lane();
@@ -166,13 +162,13 @@ struct Core {
   }
   static SF_DEV void srand_(Arena &S, const uint8_t *lds, const Params &p, uint64_t tb, uint64_t us) {  // RN:64-76
     S.rl = V(RL_ZERO);
-    S.la_ok = 0u;
     seed_digits(S.rus, us);
     seed_digits(S.rseed, tb, 1u);
     S.rs4 = S.rseed << 2;
     S.jomle = 18u;
     (void)lds;
     for (int i = 0; i < 1024; ++i) draw_core<false>(S.rl, S.rus, S.rseed, S.jomle, S.xt, p);
+    draw_issue(S, p);
   }
   // advance the next episode's warm-up by up to n draws
   // One warm-up draw of the NEXT episode's generator.  Past its first 18 draws (no zero left in the state) it runs in
@@ -181,11 +177,11 @@ struct Core {
   // of (rl2, warm) and is dropped at store time like `S.la`.
   static SF_DEV void prewarm_issue(Arena &S, const Params &p) {
     const V m4 = W::mul24(S.rl2, S.rseed2) << 2;
-    const V pr = W::mul24(W::lds_u32_at(S.xt, m4 & 0x3fcu), W::lds_u32_at(S.xt + 256, (m4 >> 8) & 0x3fcu));
+    const V pr = W::pow_pair(S.xt, m4);
     const V d = (pr & 0xffffu) - (pr >> 16);
     const V x = W::sum18_row1(S.rus * d) + SUM_BIAS;
     const V t = (x & 0xffffu) - (x >> 16);
-    S.la2 = W::gload_u16(p.logt, t + (uint32_t)LOGT_OFF, W::all());
+    S.la2 = W::gload_u16_at(p.logt, (t << 1) + 2u * (uint32_t)LOGT_OFF);
     S.la2_ok = 1u;
   }
   static SF_DEV void prewarm_one(Arena &S, const Params &p) {
@@ -995,7 +991,6 @@ struct Core {
   static SF_DEV void reset_state(Arena &S, uint8_t *lds, const Params &p, uint64_t tb, uint64_t serial, bool adopt) {
     S.frame = S.kills = S.tkills = S.loot = S.chests = S.steps = 0;
     S.done = 0, S.outcome = SF_RUNNING;
-    S.draws = 0u;
     S.tb_lo = (uint32_t)tb, S.tb_hi = (uint32_t)(tb >> 32), S.sr_lo = (uint32_t)serial, S.sr_hi = (uint32_t)(serial >> 32);
     S.hpos = V(POS_NONE), S.hfl = V(0u), S.hhp = V(0u), S.hst = V(0u), S.hmd = V(0u), S.hk = V(0u), S.hdm = V(0u);
     S.hef = V(0u), S.hc01 = V(0u), S.hc23 = V(0u), S.ht01 = V(0u), S.ht23 = V(0u), S.hbpk = V(0u);
@@ -1009,7 +1004,7 @@ struct Core {
     if (adopt) {
       prewarm(S, lds, p, 1024u);  // whatever is still missing
       S.rl = S.rl2, S.rseed = S.rseed2, S.rs4 = S.rseed2 << 2, S.jomle = 18u + 1024u;
-      S.la_ok = 0u;
+      draw_issue(S, p);
     } else {
       srand_(S, lds, p, tb, serial);
     }
@@ -1141,10 +1136,10 @@ struct Core {
     S.ended = (int32_t)W::readlane(sc, SC_ENDED);
     S.tb_lo = W::readlane(sc, SC_TB_LO), S.tb_hi = W::readlane(sc, SC_TB_HI);
     S.sr_lo = W::readlane(sc, SC_SR_LO), S.sr_hi = W::readlane(sc, SC_SR_HI);
-    S.draws = W::readlane(sc, SC_DRAWS);
     S.warm = W::readlane(sc, SC_WARM);
     if (!HBM_PLANE) W::copy_g2l(lds, p.flags + (size_t)a * (size_t)p.cells_pad, (uint32_t)p.cells_pad);
     S.dirty = 0u;
+    draw_issue(S, p);  // the lookup of the next draw (S.la) is not part of the stored state
   }
 
   static SF_DEV void store(const Arena &S, const uint8_t *lds, const Params &p, int a) {
@@ -1191,7 +1186,7 @@ struct Core {
     W::setlane(sc, SC_ENDED, (uint32_t)S.ended);
     W::setlane(sc, SC_TB_LO, S.tb_lo), W::setlane(sc, SC_TB_HI, S.tb_hi);
     W::setlane(sc, SC_SR_LO, S.sr_lo), W::setlane(sc, SC_SR_HI, S.sr_hi);
-    W::setlane(sc, SC_DRAWS, S.draws);
+    W::setlane(sc, SC_DRAWS, S.jomle - (18u + 1024u));  // _rand() calls since the episode's _srand: jomle counts them
     W::setlane(sc, SC_WARM, S.warm);
     W::gstore((uint32_t *)p.scal + (size_t)a * SC_WORDS, ln, sc, W::ltu(ln, (uint32_t)SC_WORDS));
     if (!HBM_PLANE && S.dirty) W::copy_l2g(p.flags + (size_t)a * (size_t)p.cells_pad, lds, (uint32_t)p.cells_pad);
@@ -1206,7 +1201,7 @@ struct Core {
     uint8_t *tab = lds;
     W::copy_g2l(tab, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
     S.xt = reinterpret_cast<const uint32_t *>(tab);
-    S.la = V(0u), S.la_ok = 0u;
+    S.la = V(0u);
     S.la2 = V(0u), S.la2_ok = 0u;
     return HBM_PLANE ? p.flags + (size_t)a * (size_t)p.cells_pad : lds + LDS_TABLE_BYTES;
   }

@@ -72,7 +72,11 @@ struct WaveGfx950 {
   }
   static SF_DEV V minu(V a, V b) { return a < b ? a : b; }
   // low 32 bits of a product whose operands are below 2^24 (v_mul_u32_u24)
-  static SF_DEV V mul24(V a, V b) { return __umul24(a, b); }
+  static SF_DEV V mul24(V a, V b) {
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // (the compiler picks the 32-bit multiply for __umul24)
+    return r;
+  }
   // lane i <- lane i + 1 (wave_shl:1, a gfx9 DPP control); lane 63 reads 0
   static SF_DEV V shl1(V v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 
@@ -81,9 +85,18 @@ struct WaveGfx950 {
   static SF_DEV uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return uni((uint32_t)lds[idx]); }
   static SF_DEV V lds_u32(const uint32_t *lds, V idx, P pred) { return pred ? lds[idx] : 0u; }
   static SF_DEV uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return uni(lds[idx]); }
-  // 32-bit LDS word at a byte offset (a multiple of 4), every lane
-  static SF_DEV V lds_u32_at(const uint32_t *lds, V byte_off) {
-    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lds) + byte_off);
+  // 3^lo * 3^(256 hi) from the two halves of the power table (1 KiB each, the table 2 KiB-aligned in LDS), for an
+  // exponent pre-scaled by 4: the byte offsets are bit fields of m4 OR-ed into the table's address (v_and_or_b32)
+  static SF_DEV V pow_pair(const uint32_t *xt, V m4) {
+    typedef const __attribute__((address_space(3))) uint32_t *lptr;
+    const uint32_t base = (uint32_t)(uintptr_t)(lptr)xt;
+    const uint32_t a = *(lptr)(uintptr_t)((m4 & 0x3fcu) | base);
+    const uint32_t b = *((lptr)(uintptr_t)(((m4 >> 8) & 0x3fcu) | base) + 256);  // second half: DS offset 1024
+    return mul24(a, b);
+  }
+  // 16-bit global load at a 32-bit byte offset from a wave-uniform base (saddr + voffset form), every lane
+  static SF_DEV V gload_u16_at(const uint16_t *base, V byte_off) {
+    return (uint32_t) * reinterpret_cast<const SF_GLOBAL uint16_t *>(reinterpret_cast<const SF_GLOBAL char *>(gptr(base)) + byte_off);
   }
   static SF_DEV void ulds_store_u8(uint8_t *lds, uint32_t idx, uint32_t val) {
     lds[idx] = (uint8_t)val;  // every lane writes the same byte: no divergence, one LDS pass

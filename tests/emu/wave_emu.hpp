@@ -194,10 +194,16 @@ struct WaveEmu {
     return r;
   }
   static uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return lds[idx]; }
-  static V lds_u32_at(const uint32_t *lds, const V &byte_off) {
+  static V pow_pair(const uint32_t *xt, const V &m4) {
     EMU_OP();
     V r;
-    for (int i = 0; i < 64; ++i) r.v[i] = lds[byte_off.v[i] >> 2];
+    for (int i = 0; i < 64; ++i) r.v[i] = xt[(m4.v[i] >> 2) & 255u] * xt[256 + ((m4.v[i] >> 10) & 255u)];
+    return r;
+  }
+  static V gload_u16_at(const uint16_t *base, const V &byte_off) {
+    EMU_OP();
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = base[byte_off.v[i] >> 1];
     return r;
   }
   static V lds_u16(const uint16_t *lds, const V &idx, P pred) {
