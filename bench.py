@@ -118,24 +118,47 @@ def main():
     cmds, _ = config.bench_commands(args.arenas, cfg.n_agents, total, seed0=shard.command_seed(w, rank))
     d_cmds = torch.from_numpy(cmds).cuda()  # resident in HBM before the timed region
     stride = args.arenas * cfg.n_agents
-    res_local = torch.zeros(args.arenas * cfg.n_agents * 8, dtype=torch.int32, device="cuda")
-    res_all = torch.zeros(world * res_local.numel(), dtype=torch.int32, device="cuda") if world > 1 else None
+    # end-of-episode result records, all-gathered over RCCL after every launch.  The gather of launch i
+    # runs on RCCL's stream while launch i+1 computes: two buffer pairs, and a launch only waits for the gather that
+    # used its pair two launches ago.  SF_BENCH_FORCE_GATHER=1 exercises this path with one rank.
+    gather = world > 1 or os.environ.get("SF_BENCH_FORCE_GATHER") == "1"
+    if gather and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+    n_rec = args.arenas * cfg.n_agents * 8
+    res_local = [torch.zeros(n_rec, dtype=torch.int32, device="cuda") for _ in range(2)]
+    res_all = [torch.zeros(world * n_rec, dtype=torch.int32, device="cuda") for _ in range(2)] if gather else None
+    pending = [None, None]
+    launches = [0]
 
     def run(first, count):
         s = first
         while s < first + count:
             k = min(args.k_per_launch, first + count - s)
             g.step_device(d_cmds.data_ptr() + s * stride, k)
-            if world > 1:  # end-of-episode result records, RCCL over xGMI
-                g.results_device(res_local.data_ptr())
+            if gather:
+                j = launches[0] & 1
+                launches[0] += 1
+                if pending[j] is not None:
+                    pending[j].wait()  # stream-level: this pair's previous gather is done before it is overwritten
+                    pending[j] = None
+                g.results_device(res_local[j].data_ptr())
                 if backend == "nccl":
-                    dist.all_gather_into_tensor(res_all, res_local)
+                    pending[j] = dist.all_gather_into_tensor(res_all[j], res_local[j], async_op=True)
                 else:  # rehearsal backend: through host memory
                     torch.cuda.current_stream().synchronize()
-                    shard.gather_results(res_local.cpu(), world)
+                    shard.gather_results(res_local[j].cpu(), world)
             s += k
 
+    def drain():
+        for j in range(2):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
+
     run(0, args.warmup)
+    drain()
     torch.cuda.synchronize()
     g.kernel_time(True)  # start timing step launches with HIP events on the launch stream
     if world > 1:
@@ -143,6 +166,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
+    drain()  # the gathers belong to the job: all of them are finished inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -273,7 +297,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
