@@ -202,3 +202,39 @@ def test_gemm_kernel_matches_torch(M, N, K):
     want = a.astype(np.float64) @ w.astype(np.float64).T + bias
     bound = 2e-6 * (np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T) + 1e-6
     assert (np.abs(dc.cpu().numpy() - want) <= bound).all()
+
+
+def test_hip_path_reproduces_the_committed_vectors():
+    """tests/golden/policy_vectors.json (made by the torch restatement on the CPU): the GPU simulator's observations of
+    the same seeded run through the HIP network give the committed probabilities, values and state checksums."""
+    import json
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "policy_vectors.json")))
+    A = want["arenas"]
+    w = config.baseline_workload(want["workload"], arenas=A)
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    between = want["sim_steps_between"]
+    cmds, _ = config.bench_commands(A, w.cfg.n_agents, len(want["steps"]) * between)
+    pb = policy.PolicyBatch(policy.init_parameters(seed=want["param_seed"]), A)
+    d_obs = torch.zeros((A, 32, 31, 31), dtype=torch.float32, device="cuda")
+    d_probs = torch.zeros((A, 9), dtype=torch.float32, device="cuda")
+    d_value = torch.zeros(A, dtype=torch.float32, device="cuda")
+    d_cmd = torch.zeros(A, dtype=torch.uint8, device="cuda")
+    d_act = torch.zeros(A, dtype=torch.int32, device="cuda")
+    for t, step in enumerate(want["steps"]):
+        for s in range(t * between, (t + 1) * between):
+            g.step(cmds[s])
+        g.observe_device(d_obs.data_ptr())
+        pb.forward(d_obs.data_ptr(), A, d_probs.data_ptr(), d_value.data_ptr())
+        # feed back the arg-max of the raw probabilities, as the generator did
+        acts = d_probs.cpu().numpy().argmax(axis=1)
+        assert acts.tolist() == step["action_fed_back"]
+        for b in range(A):
+            h, _ = pb.get_memory(b)
+            pb.set_memory(b, h, np.eye(9, dtype=np.float32)[acts[b]])
+        g.synchronize()
+        assert int((d_obs != 0).sum().item()) == step["obs_nonzero"]
+        np.testing.assert_allclose(d_probs.cpu().numpy(), step["probs"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(d_value.cpu().numpy(), step["value"], rtol=RTOL, atol=ATOL)
+        hs = [float(np.abs(np.stack([pb.get_memory(b)[0][gi] for b in range(A)])).sum()) for gi in range(2)]
+        np.testing.assert_allclose(hs, step["h_abs_sum"], rtol=RTOL)

@@ -94,3 +94,18 @@ def test_policy_rejects_bad_parameters():
     del bad["value.1.weight"]
     with pytest.raises(ValueError, match="missing"):
         policy.PolicyBatch(bad, 4)
+
+
+def test_restatement_reproduces_the_committed_vectors():
+    """tests/golden/policy_vectors.json is regenerated bit-for-bit up to the f32 round-off of another torch build."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_policy_vectors
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "policy_vectors.json")))
+    got = make_policy_vectors.run()
+    assert [s["action_fed_back"] for s in got["steps"]] == [s["action_fed_back"] for s in want["steps"]]
+    assert [s["obs_nonzero"] for s in got["steps"]] == [s["obs_nonzero"] for s in want["steps"]]
+    for g, w in zip(got["steps"], want["steps"]):
+        np.testing.assert_allclose(g["probs"], w["probs"], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(g["value"], w["value"], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(g["h_abs_sum"], w["h_abs_sum"], rtol=2e-5)
