@@ -46,7 +46,7 @@ static __device__ __forceinline__ void lds_barrier() {
 
 constexpr int OBS_CLASS_RECS = 8;   // shared records of plain static cells: '#', '^', 'v', 'O', chest types 0-3
 constexpr int OBS_REC_MAX = 72;     // + cells with an entity or a player-built object on them (own record each)
-constexpr int OBS_LIST_MAX = 512;  // (a) values that need a real pow, (b) overflow cells' outputs
+constexpr int OBS_LIST_MAX = 256;  // (a) values that need a real pow, (b) overflow cells' outputs
 constexpr uint32_t OBS_NOREC = 255u;
 
 // One workgroup per (arena, agent).  The 123 KB observation is written exactly once, with 16-B-per-lane stores
@@ -77,7 +77,7 @@ static __device__ __forceinline__ uint32_t obs_class_flags(int c) {
        : (uint32_t)SF_CELL_CHEST | ((uint32_t)(c - 4) << SF_CELL_CONS_SHIFT);
 }
 
-__global__ __launch_bounds__(OBS_THREADS, 4) void k_observe(Params p, float *out) {
+__global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ent[];  // [13][H] humans, [3][Z] zombies, [4][B] bullets
   __shared__ float rec[OBS_REC_MAX][SF_OBS_CHANNELS];
   __shared__ uint32_t occ[OBS_W2];
