@@ -1,0 +1,39 @@
+"""Closed loop on one MI355X with nothing leaving HBM: observe -> bot-0.5 network -> sample -> step.
+
+    python examples/policy_loop.py [arenas] [steps]
+
+The network's parameters are random here (same shapes and initialisers as the reference's AgentModel); pass a dict
+of numpy arrays keyed by the reference's parameter names to `PolicyBatch` to run a trained model.
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from strikeforce_amd import config, env, policy
+
+arenas = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+w = config.baseline_workload("C2", arenas=arenas)           # 64x64 map, 1 player + 16 zombies, auto-reset
+sim = env.ArenaBatch(w)
+sim.reset(*w.seeds())
+agents = arenas * w.cfg.n_agents
+net = policy.PolicyBatch(policy.init_parameters(seed=0), agents)
+d_obs = torch.empty((agents, 32, 31, 31), dtype=torch.float32, device="cuda")
+d_probs = torch.empty((agents, 9), dtype=torch.float32, device="cuda")
+d_value = torch.empty(agents, dtype=torch.float32, device="cuda")
+d_cmd = torch.zeros(agents, dtype=torch.uint8, device="cuda")
+t0 = time.perf_counter()
+for t in range(steps):
+    sim.observe_device(d_obs.data_ptr())                                            # gameplay::bot()'s encoding
+    net.forward(d_obs.data_ptr(), agents, d_probs.data_ptr(), d_value.data_ptr())   # AgentModel::forward
+    net.act(d_probs.data_ptr(), agents, d_cmd.data_ptr(), seed=1234)                # Agent::predict's sampling + update
+    sim.step_device(d_cmd.data_ptr(), 1)                                            # one tick of every arena
+sim.synchronize()
+net.synchronize()
+dt = time.perf_counter() - t0
+res = sim.results()
+print("%d arenas x %d steps in %.2f s = %.2f M agent-steps/s; kills so far: %d; mean state value %.3f"
+      % (arenas, steps, dt, agents * steps / dt / 1e6, int(res[:, :, 0].sum()), float(d_value.mean())))
