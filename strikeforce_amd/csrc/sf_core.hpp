@@ -422,10 +422,11 @@ struct Core {
     const V zr = (zq >> 10) & 1023u, zc = zq & 1023u;
     // neighbour d of each zombie: packed position and "clear flag byte" bit
     V freebits = V(0u);
+    const V ci0 = ((zq >> 20) * (uint32_t)p.N + zr) * (uint32_t)p.M + zc;  // the zombie's own cell index
     for (int d = 0; d < 4; ++d) {
       const V rr = zr + (uint32_t)DX(d), cc = zc + (uint32_t)DY(d);
       const P inb = zalive & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
-      const V ci = ((zq >> 20) * (uint32_t)p.N + rr) * (uint32_t)p.M + cc;
+      const V ci = ci0 + (uint32_t)(DX(d) * p.M + DY(d));
       const V fl = W::lds_u8(lds, ci, inb);
       freebits = freebits | W::select(inb & (fl == 0u), V(1u << d), V(0u));
     }
