@@ -216,6 +216,7 @@ def main():
         d_probs = torch.empty(agents * 9, dtype=torch.float32, device="cuda")
         d_value = torch.empty(agents, dtype=torch.float32, device="cuda")
         d_pcmd = torch.zeros(agents, dtype=torch.uint8, device="cuda")
+        d_new = torch.zeros(agents, dtype=torch.uint8, device="cuda")
         pol_n = 10
 
         def closed_loop(n):
@@ -224,6 +225,8 @@ def main():
                 pb.forward(d_obs.data_ptr(), agents, d_probs.data_ptr(), d_value.data_ptr())
                 pb.act(d_probs.data_ptr(), agents, d_pcmd.data_ptr(), seed=rank)
                 g.step_device(d_pcmd.data_ptr(), 1)
+                g.done_device(d_new.data_ptr())      # agents whose game restarted get a fresh memory,
+                pb.reset_memory(d_new.data_ptr())    # like the reference's new Agent per game
 
         closed_loop(2)
         torch.cuda.synchronize()

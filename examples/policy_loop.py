@@ -25,12 +25,15 @@ d_obs = torch.empty((agents, 32, 31, 31), dtype=torch.float32, device="cuda")
 d_probs = torch.empty((agents, 9), dtype=torch.float32, device="cuda")
 d_value = torch.empty(agents, dtype=torch.float32, device="cuda")
 d_cmd = torch.zeros(agents, dtype=torch.uint8, device="cuda")
+d_new = torch.zeros(agents, dtype=torch.uint8, device="cuda")
 t0 = time.perf_counter()
 for t in range(steps):
     sim.observe_device(d_obs.data_ptr())                                            # gameplay::bot()'s encoding
     net.forward(d_obs.data_ptr(), agents, d_probs.data_ptr(), d_value.data_ptr())   # AgentModel::forward
     net.act(d_probs.data_ptr(), agents, d_cmd.data_ptr(), seed=1234)                # Agent::predict's sampling + update
     sim.step_device(d_cmd.data_ptr(), 1)                                            # one tick of every arena
+    sim.done_device(d_new.data_ptr())                                               # games that just restarted ...
+    net.reset_memory(d_new.data_ptr())                                              # ... get a new Agent's memory
 sim.synchronize()
 net.synchronize()
 dt = time.perf_counter() - t0

@@ -187,6 +187,10 @@ int sf_results_device(sf_env *env, int32_t *d_out);
 
 /* Replaces the loop exit test `if(check_end()) break;` gameplay.hpp:1450. */
 int sf_done(sf_env *env, uint8_t *out_host);
+/* The same flag on the device, one byte per (arena, agent) (every agent of an arena gets its arena's flag), in the
+ * layout the policy library's reset_memory entry (strikeforce_policy.h) takes: with auto_reset it marks the agents whose game just restarted, i.e. where the
+ * reference would have built a new Agent in prepare() (gameplay.hpp:481). */
+int sf_done_device(sf_env *env, uint8_t *d_out);
 
 /* ---- parity / tooling ---------------------------------------------------------------------- */
 int sf_state_digest(sf_env *env, uint64_t *out_host); /* one 64-bit digest per arena */

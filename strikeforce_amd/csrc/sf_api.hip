@@ -34,6 +34,14 @@ __global__ __launch_bounds__(64) void k_step(Params p, const uint8_t *cmds, int 
   Core<WaveGfx950, NB, HP>::step_body(lds, p, (int)blockIdx.x, cmds, k);
 }
 
+// check_end()'s verdict per (arena, agent) on the device (sf_done_device)
+__global__ void k_done(Params p, uint8_t *out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= p.A * p.n_agents) return;
+  const SF_GLOBAL int32_t *sc = gptr(p.scal) + (size_t)(i / p.n_agents) * SC_WORDS;
+  gptr(out)[i] = (uint8_t)(p.auto_reset ? sc[SC_ENDED] : sc[SC_DONE]);
+}
+
 constexpr int OBS_W2 = SF_OBS_WINDOW * SF_OBS_WINDOW;  // 961
 constexpr int OBS_THREADS = 256;
 
@@ -361,6 +369,13 @@ struct HipRT {
       default: return do_step<4>(p, cmds, k);
     }
   }
+  int launch_done(const Params &p, uint8_t *d_out) {
+    SF_HIP(hipSetDevice(device));
+    const int n = p.A * p.n_agents;
+    hipLaunchKernelGGL(k_done, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, d_out);
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+  }
   int launch_observe(const Params &p, int, float *out) {
     SF_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(k_observe, dim3((unsigned)(p.A * p.n_agents)), dim3(OBS_THREADS),
@@ -449,6 +464,10 @@ int sf_results(sf_env *env, int32_t *out_host) {
 int sf_results_device(sf_env *env, int32_t *d_out) {
   SF_ENV(env);
   return env->e.results_device(d_out);
+}
+int sf_done_device(sf_env *env, uint8_t *d_out) {
+  SF_ENV(env);
+  return env->e.done_device(d_out);
 }
 int sf_done(sf_env *env, uint8_t *out_host) {
   SF_ENV(env);

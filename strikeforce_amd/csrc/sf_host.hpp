@@ -350,6 +350,11 @@ struct Env {
     return SF_OK;
   }
 
+  int done_device(uint8_t *d_out) {
+    if (!d_out) return fail(SF_ERR_ARG, "null done buffer");
+    return rt.launch_done(p, d_out);
+  }
+
   // ---- parity tooling ----------------------------------------------------------------------------
   int snapshot() {
     const size_t A = (size_t)p.A;

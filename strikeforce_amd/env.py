@@ -45,12 +45,13 @@ def load_library():
         L.sf_step_device.argtypes = [vp, vp, C.c_int32]
         L.sf_observe_device.argtypes = [vp, vp]
         L.sf_results_device.argtypes = [vp, vp]
+        L.sf_done_device.argtypes = [vp, vp]
         L.sf_set_stream.argtypes = [vp, vp]
         L.sf_synchronize.argtypes = [vp]
         L.sf_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.sf_config_defaults.argtypes = [C.POINTER(abi.Config)]
         L.sf_config_defaults.restype = None
-        for n in ("sf_step_device", "sf_observe_device", "sf_results_device", "sf_set_stream", "sf_synchronize",
+        for n in ("sf_step_device", "sf_observe_device", "sf_results_device", "sf_done_device", "sf_set_stream", "sf_synchronize",
                   "sf_kernel_time", "sf_abi_version"):
             getattr(L, n).restype = C.c_int
         L.sf_last_error.restype = C.c_char_p
@@ -60,7 +61,7 @@ def load_library():
 
 # every symbol include/strikeforce.h declares
 EXPORTS = ["sf_create", "sf_destroy", "sf_config_defaults", "sf_reset", "sf_step", "sf_step_device", "sf_observe",
-           "sf_observe_device", "sf_results", "sf_results_device", "sf_done", "sf_state_digest", "sf_dump_arena",
+           "sf_observe_device", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
            "sf_set_stream", "sf_synchronize", "sf_kernel_time", "sf_last_error", "sf_abi_version"]
 
 
@@ -133,6 +134,10 @@ class ArenaBatch:
 
     def results_device(self, d_out_ptr):
         self._ck(self.L.sf_results_device(self.h, C.c_void_p(d_out_ptr)), "sf_results_device")
+
+    def done_device(self, d_out_ptr):
+        """check_end()'s verdict on the device, one byte per (arena, agent): what PolicyBatch.reset_memory takes."""
+        self._ck(self.L.sf_done_device(self.h, C.c_void_p(d_out_ptr)), "sf_done_device")
 
     def done(self):
         out = np.zeros(self.cfg.arenas, dtype=np.uint8)

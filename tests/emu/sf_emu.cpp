@@ -116,6 +116,13 @@ struct CpuRT {
     }
     return SF_OK;
   }
+  int launch_done(const Params &p, uint8_t *out) {
+    for (int i = 0; i < p.A * p.n_agents; ++i) {
+      const int32_t *sc = p.scal + (size_t)(i / p.n_agents) * SC_WORDS;
+      out[i] = (uint8_t)(p.auto_reset ? sc[SC_ENDED] : sc[SC_DONE]);
+    }
+    return SF_OK;
+  }
   int launch_observe(const Params &p, int, float *out) {
     run_observe(p, out);
     return SF_OK;

@@ -238,3 +238,52 @@ def test_hip_path_reproduces_the_committed_vectors():
         np.testing.assert_allclose(d_value.cpu().numpy(), step["value"], rtol=RTOL, atol=ATOL)
         hs = [float(np.abs(np.stack([pb.get_memory(b)[0][gi] for b in range(A)])).sum()) for gi in range(2)]
         np.testing.assert_allclose(hs, step["h_abs_sum"], rtol=RTOL)
+
+
+def test_closed_loop_resets_memory_when_a_game_restarts():
+    """Timer-mode arenas with a 6-frame limit restart every few steps (auto_reset): sf_done_device marks the agents
+    whose game just restarted and sf_policy_reset_memory gives them the memory of a new Agent, which is what the
+    reference does per game (prepare(), gameplay.hpp:481).  Shadowed by oracle simulator + reference network."""
+    from strikeforce_amd import abi
+    arenas, steps = 6, 14
+    cfg = config.make_config(arenas, 32, 32, H=1, Z=4, B=16, P=4, mode=abi.MODE_TIMER, n_agents=1, auto_reset=1,
+                             timer_frames=6)
+    m, pmap = config.synthetic_map(32, 32)
+    w = config.Workload("timer6", cfg, m, pmap)
+    o, g = Oracle(w), env.ArenaBatch(w)
+    tb, sr = w.seeds()
+    o.reset(tb, sr), g.reset(tb, sr)
+    B = arenas
+    params = policy.init_parameters(seed=4)
+    pb = policy.PolicyBatch(params, B)
+    d_obs = torch.zeros((B, 32, 31, 31), dtype=torch.float32, device="cuda")
+    d_probs = torch.zeros((B, 9), dtype=torch.float32, device="cuda")
+    d_value = torch.zeros(B, dtype=torch.float32, device="cuda")
+    d_cmd = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    d_act = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_new = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    h = np.zeros((2, B, 160), dtype=np.float32)
+    a = np.eye(9, dtype=np.float32)[[0] * B]
+    restarts = 0
+    for t in range(steps):
+        g.observe_device(d_obs.data_ptr())
+        pb.forward(d_obs.data_ptr(), B, d_probs.data_ptr(), d_value.data_ptr())
+        pb.act(d_probs.data_ptr(), B, d_cmd.data_ptr(), seed=2, d_action_ptr=d_act.data_ptr())
+        g.step_device(d_cmd.data_ptr(), 1)
+        g.done_device(d_new.data_ptr())
+        pb.reset_memory(d_new.data_ptr())
+        g.synchronize(), pb.synchronize()
+        probs, value, h = policy_ref.forward_batched(params, o.observe().reshape(B, 32, 31, 31), h, a)
+        np.testing.assert_allclose(d_probs.cpu().numpy(), probs, rtol=RTOL, atol=ATOL)
+        a = np.eye(9, dtype=np.float32)[d_act.cpu().numpy()]
+        o.step(d_cmd.cpu().numpy())
+        assert (o.digest() == g.digest()).all()
+        new = o.done()  # per (arena, agent): one agent per arena here
+        assert (d_new.cpu().numpy() == new).all()
+        for b in np.nonzero(new)[0]:  # reset_memory(): h_state = 0, action_input = one-hot(0)   Modules.hpp:95-100
+            h[:, b] = 0
+            a[b] = np.eye(9, dtype=np.float32)[0]
+        restarts += int(new.sum())
+    assert restarts >= arenas  # every arena restarted at least once
+    hg, ag = pb.get_memory(0)
+    np.testing.assert_allclose(hg, h[:, 0], rtol=RTOL, atol=ATOL * 10)
