@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--arenas", type=int, default=4096, help="arenas per GPU")
-    ap.add_argument("--k-per-launch", type=int, default=50, help="loop iterations per kernel launch")
+    ap.add_argument("--k-per-launch", type=int, default=100, help="loop iterations per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-interactive", action="store_true", help="skip the K=1 + observation measurement")
     ap.add_argument("--no-policy", action="store_true", help="skip the closed loop with the on-device policy network")

@@ -2,7 +2,7 @@
 # wait/ifetch/LDS breakdown of the step kernel (separate PMC passes)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 rm -rf gpurun_out/pmc2 && mkdir -p gpurun_out/pmc2
-ARGS="--steps 200 --warmup 400 --no-cpu-baseline --no-interactive"
+ARGS="--steps 200 --warmup 400 --k-per-launch 50 --no-cpu-baseline --no-interactive"
 rocprofv3 -L > gpurun_out/pmc2/counters.txt 2>&1
 grep -o "SQC_ICACHE[A-Z_]*\|SQ_IFETCH[A-Z_]*\|SQ_WAIT_IFETCH[A-Z_]*\|SQ_INST_LEVEL[A-Z_]*\|SQ_WAIT_INST_LDS\|SQ_INSTS_EXP_GDS\|SQC_DCACHE[A-Z_]*" gpurun_out/pmc2/counters.txt | sort -u | tr '\n' ' '
 echo
