@@ -64,9 +64,18 @@ def cpu_baseline(workload_name, seconds=12.0):
         dt = time.perf_counter() - t0
         if dt >= seconds:
             break
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d arenas of %s, %d arena-steps in %.1f s, oracle/sf_oracle.c single thread"
-                      % (arenas, workload_name, steps, dt)}
+            "sample": "%d arenas of %s, %d arena-steps in %.1f s, oracle/sf_oracle.c single thread on %s (host has %d "
+                      "logical cores; the reference loop is single-threaded, gameplay.hpp:1443)"
+                      % (arenas, workload_name, steps, dt, model, os.cpu_count() or 0)}
 
 
 def main():
