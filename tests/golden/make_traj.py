@@ -16,22 +16,29 @@ sys.path.insert(0, os.path.dirname(HERE))
 from oracle_lib import Oracle  # noqa: E402
 from strikeforce_amd import config  # noqa: E402
 
-CASES = [("C1", 2, 300), ("C2", 2, 300), ("C3", 2, 200), ("C4", 2, 100), ("C5", 2, 60), ("STRESS", 2, 300),
-         ("FLOORS", 2, 200), ("MAXCAP", 1, 60), ("NATIVE", 2, 400)]
+# lengths after SURVEY.md §8c: the native world for 2000 steps on three seeds, every BASELINE configuration for 1000
+CASES = [("C1", 2, 1000), ("C2", 2, 1000), ("C3", 2, 1000), ("C4", 2, 1000), ("C5", 2, 1000), ("STRESS", 2, 400),
+         ("FLOORS", 2, 400), ("MAXCAP", 1, 100), ("NATIVE", 3, 2000)]
 CHECKPOINTS = 4
 
 
-def run_case(name, arenas, steps, make=Oracle):
+def run_case(name, arenas, steps, make=Oracle, obs=True):
+    """{"digests": {step: [digest per arena]}, "obs_crc": {step: crc32 of every agent's 32x31x31 float32 observation}}.
+    The digest covers every state word including jomle, i.e. the number of RNG draws so far.  The observation CRC is
+    bit-exact and therefore only compared between CPU implementations (the GPU's pow may differ by one ulp)."""
+    import zlib
     w = config.baseline_workload(name, arenas=arenas)
     sim = make(w)
     tb, sr = w.seeds()
     sim.reset(tb, sr)
     cmds, _ = config.bench_commands(arenas, w.cfg.n_agents, steps)
-    out = {"0": [int(x) for x in sim.digest()]}
+    out = {"digests": {"0": [int(x) for x in sim.digest()]}, "obs_crc": {}}
     chunk = steps // CHECKPOINTS
     for c in range(CHECKPOINTS):
         sim.step_many(cmds[c * chunk:(c + 1) * chunk])
-        out[str((c + 1) * chunk)] = [int(x) for x in sim.digest()]
+        out["digests"][str((c + 1) * chunk)] = [int(x) for x in sim.digest()]
+        if obs:
+            out["obs_crc"][str((c + 1) * chunk)] = zlib.crc32(sim.observe().tobytes())
     return out
 
 

@@ -35,4 +35,4 @@ def test_gpu_reproduces_the_fixtures(key):
                 self.step(np.ascontiguousarray(c))
 
     name, arenas, steps = key.split("/")
-    assert make_traj.run_case(name, int(arenas), int(steps), Gpu) == GOLD[key]
+    assert make_traj.run_case(name, int(arenas), int(steps), Gpu, obs=False)["digests"] == GOLD[key]["digests"]
