@@ -61,6 +61,10 @@ struct Gemm {
   // gridDim.x blocks in contiguous runs of unit_base (+1 for the first unit_rem blocks) units
   int ntiles, unit_base, unit_rem;
   float *part;        // [gridDim.y][gridDim.x][2][BM*160] partial tiles of runs that start or end inside a tile
+  // an independent second product of the same shape, computed by the blocks with blockIdx.z == 1 (one launch for
+  // the two gate products of a GRU cell, or for the same layer of the two heads)
+  const float *A2, *W2, *bias2;
+  float *C2;
 };
 
 constexpr int BN = 160;
@@ -84,6 +88,7 @@ __device__ inline int run_owner(const Gemm &g, int u) {
 // (deterministic: no atomics).
 template <int WM, int WN, int BKT, int MODE>
 __global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm(Gemm g) {
+  if (blockIdx.z) g.A = g.A2, g.W = g.W2, g.bias = g.bias2, g.C = g.C2;
   constexpr int T = WM * WN * 64, BM = WM * 32, LD = BKT + 1;
   constexpr int NT = 5 / WN;                    // 32-column tiles per wave
   constexpr int Q = BKT / 4;                    // float4 per tile row
@@ -385,9 +390,11 @@ __device__ inline Row3 gru_cell(const float *gi, const float *gh, const Row3 &h,
   const int a = blockIdx.x * 4 + (threadIdx.x >> 6); \
   if (a >= agents) return;
 
-__global__ __launch_bounds__(256) void k_norm(const float *x, float *y, int agents) {
+__global__ __launch_bounds__(256) void k_norm(const float *x, float *y, float *y2, int agents) {  // y2: optional copy
   SFP_ROW_PROLOGUE
-  row_store(y + (size_t)a * HID, l, row_norm(row_load(x + (size_t)a * HID, l)));
+  const Row3 r = row_norm(row_load(x + (size_t)a * HID, l));
+  row_store(y + (size_t)a * HID, l, r);
+  if (y2) row_store(y2 + (size_t)a * HID, l, r);
 }
 
 // gru0 + the assembly of `combined` (Modules.hpp:110-123): comb[0:160] = norm(h0') + feat_n,
@@ -445,9 +452,11 @@ __global__ __launch_bounds__(256) void k_gru1(const float *gi, const float *gh, 
   row_store(out + (size_t)a * HID, l, o);
 }
 
-// one ResB layer after its Linear (Modules.hpp:45-46): x <- norm(relu(lin) + x)
-__global__ __launch_bounds__(256) void k_res(const float *lin, float *x, int agents) {
+// one ResB layer after its Linear (Modules.hpp:45-46): x <- norm(relu(lin) + x); blockIdx.y picks the head
+__global__ __launch_bounds__(256) void k_res(const float *lin0, float *x0, const float *lin1, float *x1, int agents) {
   SFP_ROW_PROLOGUE
+  const float *lin = blockIdx.y ? lin1 : lin0;
+  float *x = blockIdx.y ? x1 : x0;
   float *xp = x + (size_t)a * HID;
   const Row3 y = row_load(lin + (size_t)a * HID, l), xv = row_load(xp, l);
   Row3 r;
@@ -563,7 +572,7 @@ struct Policy {
   float *h[2] = {}, *action_input = nullptr;
   float *act[3] = {};  // NHWC conv outputs 15x15, 7x7, 3x3
   float *feat = nullptr, *feat_n = nullptr, *gi = nullptr, *gh = nullptr, *comb = nullptr, *gated = nullptr,
-        *gated_n = nullptr, *out = nullptr, *x[2] = {}, *lin = nullptr;
+        *gated_n = nullptr, *out = nullptr, *x[2] = {}, *lin[2] = {};
   std::vector<void *> owned;
   // timing of the GEMM launches
   bool timing = false;
@@ -601,9 +610,9 @@ struct Policy {
     g.part = part;
     const long units = (long)g.ntiles * KT;
     int G = g.ntiles;  // one run per row tile: the classic decomposition
-    if (WN == 1 && g.N == BN && units >= 4L * sk_blocks) G = sk_blocks;
+    if (WN == 1 && g.N == BN && !g.A2 && units >= 4L * sk_blocks) G = sk_blocks;
     g.unit_base = (int)(units / G), g.unit_rem = (int)(units % G);
-    hipLaunchKernelGGL((k_gemm<WM, WN, BKT, MODE>), dim3((unsigned)G, (unsigned)(g.N / BN)), dim3(WM * WN * 64), 0, stream, g);
+    hipLaunchKernelGGL((k_gemm<WM, WN, BKT, MODE>), dim3((unsigned)G, (unsigned)(g.N / BN), g.A2 ? 2u : 1u), dim3(WM * WN * 64), 0, stream, g);
     if (G != g.ntiles)
       hipLaunchKernelGGL((k_gemm_fixup<WM * 32>), dim3((unsigned)(G - 1), (unsigned)(g.N / BN)), dim3(256), 0, stream, g, KT, G);
   }
@@ -624,7 +633,7 @@ struct Policy {
       }
       e0 = events[used_events].first, e1 = events[used_events].second;
       ++used_events;
-      flop += 2.0 * g.M * g.N * g.K;
+      flop += 2.0 * g.M * g.N * g.K * (g.A2 ? 2 : 1);
       SFP_HIP(hipEventRecord(e0, stream));
     }
     switch (mode) {
@@ -637,12 +646,18 @@ struct Policy {
     return SF_OK;
   }
   int dense(const float *A, int lda, const float *W, const float *bias, float *C, int ldc, int M, int N, int K) {
-    Gemm g{A, W, bias, C, M, N, K, lda, ldc, 0, 0, 0, 0, 0, 0, nullptr};
+    Gemm g{A, W, bias, C, M, N, K, lda, ldc, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return gemm(g, MODE_DENSE);
+  }
+  // two independent products of one shape in one launch
+  int dense2(const float *A, const float *W, const float *bias, float *C, const float *A2, const float *W2,
+             const float *bias2, float *C2, int lda, int ldc, int M, int N, int K) {
+    Gemm g{A, W, bias, C, M, N, K, lda, ldc, 0, 0, 0, 0, 0, 0, nullptr, A2, W2, bias2, C2};
     return gemm(g, MODE_DENSE);
   }
   int conv(const float *in, const float *W, float *outp, int agents, int S, int Cin, int nchw) {
     const int So = (S - 3) / 2 + 1;
-    Gemm g{in, W, nullptr, outp, agents * So * So, HID, Cin * 9, 0, HID, S, Cin, So, 0, 0, 0, nullptr};
+    Gemm g{in, W, nullptr, outp, agents * So * So, HID, Cin * 9, 0, HID, S, Cin, So, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     return gemm(g, nchw ? MODE_NCHW : MODE_NHWC);
   }
 };
@@ -727,7 +742,8 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
   SFP_TRY(p->dalloc(&p->out, B * HID));
   SFP_TRY(p->dalloc(&p->x[0], B * HID));
   SFP_TRY(p->dalloc(&p->x[1], B * HID));
-  SFP_TRY(p->dalloc(&p->lin, B * HID));
+  SFP_TRY(p->dalloc(&p->lin[0], B * HID));
+  SFP_TRY(p->dalloc(&p->lin[1], B * HID));
   SFP_TRY(p->dalloc(&p->part, (size_t)p->sk_blocks * 2 * 128 * BN));
 #undef SFP_TRY
   *out = reinterpret_cast<sf_policy *>(p);
@@ -746,25 +762,28 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
   if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, HID, 0))) return rc;
   if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, HID, 0))) return rc;
   if ((rc = p->conv(p->act[2], p->conv_w[3], p->feat, agents, 3, HID, 0))) return rc;
-  hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->feat, p->feat_n, agents);                     // :108
-  // gru0                                                                                       :110-113
-  if ((rc = p->dense(p->feat_n, HID, p->gru_w_ih[0], p->gru_b_ih[0], p->gi, G3, agents, G3, HID))) return rc;
-  if ((rc = p->dense(p->h[0], HID, p->gru_w_hh[0], p->gru_b_hh[0], p->gh, G3, agents, G3, HID))) return rc;
+  float *const none = nullptr;
+  hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->feat, p->feat_n, none, agents);               // :108
+  // gru0 (both gate products in one launch)                                                    :110-113
+  if ((rc = p->dense2(p->feat_n, p->gru_w_ih[0], p->gru_b_ih[0], p->gi, p->h[0], p->gru_w_hh[0], p->gru_b_hh[0], p->gh,
+                      HID, G3, agents, G3, HID)))
+    return rc;
   hipLaunchKernelGGL(k_gru0, rg, rb, 0, st, p->gi, p->gh, p->h[0], p->feat_n, d_obs, p->action_input, p->comb, agents);
   // combined_processor                                                                         :125-126
   if ((rc = p->dense(p->comb, COMB_PAD, p->comb_w, p->comb_b, p->gated, HID, agents, HID, COMB_PAD))) return rc;
-  hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->gated, p->gated_n, agents);
+  hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->gated, p->gated_n, none, agents);
   // gru1                                                                                       :128-131
-  if ((rc = p->dense(p->gated_n, HID, p->gru_w_ih[1], p->gru_b_ih[1], p->gi, G3, agents, G3, HID))) return rc;
-  if ((rc = p->dense(p->h[1], HID, p->gru_w_hh[1], p->gru_b_hh[1], p->gh, G3, agents, G3, HID))) return rc;
+  if ((rc = p->dense2(p->gated_n, p->gru_w_ih[1], p->gru_b_ih[1], p->gi, p->h[1], p->gru_w_hh[1], p->gru_b_hh[1], p->gh,
+                      HID, G3, agents, G3, HID)))
+    return rc;
   hipLaunchKernelGGL(k_gru1, rg, rb, 0, st, p->gi, p->gh, p->h[1], p->gated_n, p->out, agents);
-  // heads: ResB then Linear                                                                    :41-48,172-175
-  for (int hd = 0; hd < 2; ++hd) {
-    hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->out, p->x[hd], agents);
-    for (int i = 0; i < 3; ++i) {
-      if ((rc = p->dense(p->x[hd], HID, p->res_w[hd][i], p->res_b[hd][i], p->lin, HID, agents, HID, HID))) return rc;
-      hipLaunchKernelGGL(k_res, rg, rb, 0, st, p->lin, p->x[hd], agents);
-    }
+  // heads: ResB then Linear; layer i of both heads shares a launch                             :41-48,172-175
+  hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->out, p->x[0], p->x[1], agents);
+  for (int i = 0; i < 3; ++i) {
+    if ((rc = p->dense2(p->x[0], p->res_w[0][i], p->res_b[0][i], p->lin[0], p->x[1], p->res_w[1][i], p->res_b[1][i],
+                        p->lin[1], HID, HID, agents, HID, HID)))
+      return rc;
+    hipLaunchKernelGGL(k_res, dim3(rg.x, 2), rb, 0, st, p->lin[0], p->x[0], p->lin[1], p->x[1], agents);
   }
   hipLaunchKernelGGL(k_heads, rg, rb, 0, st, p->x[0], p->x[1], p->head_w[0], p->head_b[0], p->head_w[1], p->head_b[1],
                      d_probs, d_value, agents);
