@@ -610,7 +610,7 @@ struct Policy {
     g.part = part;
     const long units = (long)g.ntiles * KT;
     int G = g.ntiles;  // one run per row tile: the classic decomposition
-    if (WN == 1 && g.N == BN && !g.A2 && units >= 4L * sk_blocks) G = sk_blocks;
+    if (g.N == BN && !g.A2 && units >= 4L * sk_blocks) G = sk_blocks;  // (both block shapes: conv3 is the small-M case)
     g.unit_base = (int)(units / G), g.unit_rem = (int)(units % G);
     hipLaunchKernelGGL((k_gemm<WM, WN, BKT, MODE>), dim3((unsigned)G, (unsigned)(g.N / BN), g.A2 ? 2u : 1u), dim3(WM * WN * 64), 0, stream, g);
     if (G != g.ntiles)
