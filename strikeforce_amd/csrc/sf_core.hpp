@@ -64,21 +64,9 @@ struct Core {
 
   // ------------------------------------------------------------------------------------------------
   // RNG: 18-tap generator over Z/65537, RN:27-77.  Taps are lane-parallel, the mod-exp is wave-uniform.
-  static SF_DEV uint32_t mulmod_u(uint32_t a, uint32_t b) {  // a, b in [0, 65536]
-    uint32_t p = a * b;                                      // wraps only for 65536*65536 = 2^32 == 1 (mod 65537)
-    int32_t r = (int32_t)(p & 0xffffu) - (int32_t)(p >> 16) + (int32_t)((a & b) >> 16);
-    r += (r >> 31) & 65537;
-    return (uint32_t)r;
-  }
-  static SF_DEV V mulmod_v(V a, V b) {
-    V p = a * b;
-    V r = (p & 0xffffu) - (p >> 16) + ((a & b) >> 16);
-    return r + (W::sar31(r) & 65537u);
-  }
-
   // Z/65537* is cyclic of order 65536 with generator 3, so x^e = 3^(log3(x) * e mod 65536).  The state keeps
-  // log3(random[i]); a power is then two 256-entry LDS lookups (3^lo, 3^(256 hi)) and one mulmod instead of a
-  // 16-step square-and-multiply chain, and the new value's log is one HBM/L2 lookup in the 64 Ki-entry log table.
+  // log3(random[i]); a power is then two 256-entry LDS lookups (3^lo, 3^(256 hi)) and one multiply instead of a
+  // 16-step square-and-multiply chain, and the new value's log is one L2 lookup in the log table (sf_types.hpp LOGT_*).
   // Bit-identical to RN:54-62 by construction (checked against the reference's known answers).
   static constexpr uint32_t RL_ZERO = 0x10000u;  // random[i] == 0 (only until the first 18 draws after _srand)
   // x mod 65537 for x < 2^32: lo16 - hi16, plus 65537 if that went negative (as unsigned: the smaller of the two)
@@ -91,13 +79,10 @@ struct Core {
     return mod65537_v(W::lds_u32(xt, m & 255u, pred) * W::lds_u32(xt + 256, m >> 8, pred));
   }
 
-  // The scalar unit is shared by the four SIMDs of a CU and is this kernel's scarcest resource (measured:
-  // SQ_INSTS_SALU ~ SQ_INSTS_VALU, one scalar issue per cycle per CU), so the wave-uniform tail of a draw
-  // (mod, log lookup, power) is deliberately computed on the vector unit, redundantly in every lane, and only the
-  // 10-bit result goes back to an SGPR.
-  // (Tried and dropped: a 16-arena workgroup sharing a 64 KiB LDS copy of the log table — log3(65537 - x) =
-  // log3(x) + 32768 halves it — measured equal to this L2 lookup within 2 %: the chain is bound by its ~45
-  // dependent ALU ops, not by the lookup.)
+  // draw_core is the general form of RN:54-62 (zero-valued taps allowed): _srand's warm-up and the first draws of a
+  // fresh generator use it.  The wave-uniform tail of a draw (mod, log lookup, power) is computed on the vector unit,
+  // redundantly in every lane: the scalar unit is shared by the four SIMDs of a CU and was the first bottleneck
+  // measured (SQ_INSTS_SALU ~ SQ_INSTS_VALU).  The hot path is draw() / draw_issue() below.
   template <bool WANT_OUT>
   static SF_DEV V draw_core(V &rl, const V &rus, const V &rseed, uint32_t &jomle, const uint32_t *xt, const Params &p) {
     const P tap = W::ltu(W::lane(), 18u) & ((rl & RL_ZERO) == 0u);
@@ -109,7 +94,6 @@ struct Core {
     t = W::select(t == 0u, V(1u), t);  // binpow(sum + (int)(sum == 0), ...)
     jomle += 1u;
     const uint32_t e = jomle & 0xffffu;  // b %= mod - 1
-    // (& 65535: lanes outside 16..31 hold junk and must still read inside the table)
     const V lg = W::gload_u16(p.logt, t + (uint32_t)LOGT_OFF, W::all());  // t <= 65536 whatever a junk lane summed
     const V lnew = (lg * e) & 0xffffu;
     rl = W::select(W::lane() == 17u, lnew, W::shl1(rl));  // the 17 swaps: rotate left, new value last

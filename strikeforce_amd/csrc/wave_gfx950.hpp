@@ -50,15 +50,6 @@ struct WaveGfx950 {
   static SF_DEV P ltu(V a, V b) { return a < b; }
   static SF_DEV P frombits(uint64_t m) { return (m >> lane()) & 1ull; }
   static SF_DEV P all() { return true; }
-  // a wave-uniform value moved to a VGPR behind the optimiser's back, so that what is computed from it stays on
-  // the vector unit (the scalar unit is shared by the CU's four SIMDs and is this kernel's bottleneck)
-  static SF_DEV V vec(uint32_t x) {
-    uint32_t r;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
-    return r;
-  }
-  static SF_DEV uint32_t first(V v) { return uni(v); }
-
   // sum over lanes 0..17 of a value that is zero on lanes >= 18, left on the vector unit: valid on lanes 16..31
   // (DPP reductions inside each 16-lane row, then row 1 += row 0's total via row_bcast:15)
   static SF_DEV V sum18_row1(V v) {
@@ -84,7 +75,6 @@ struct WaveGfx950 {
   static SF_DEV V lds_u8(const uint8_t *lds, V idx, P pred) { return pred ? (uint32_t)lds[idx] : 0u; }
   static SF_DEV uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return uni((uint32_t)lds[idx]); }
   static SF_DEV V lds_u32(const uint32_t *lds, V idx, P pred) { return pred ? lds[idx] : 0u; }
-  static SF_DEV uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return uni(lds[idx]); }
   // 3^lo * 3^(256 hi) from the two halves of the power table (1 KiB each, the table 2 KiB-aligned in LDS), for an
   // exponent pre-scaled by 4: the byte offsets are bit fields of m4 OR-ed into the table's address (v_and_or_b32)
   static SF_DEV V pow_pair(const uint32_t *xt, V m4) {

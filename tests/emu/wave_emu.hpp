@@ -151,8 +151,6 @@ struct WaveEmu {
   }
   static P frombits(uint64_t m) { return P{m}; }
   static P all() { return P{~0ull}; }
-  static V vec(uint32_t x) { return V(x); }
-  static uint32_t first(const V &v) { return v.v[0]; }
   static V sum18_row1(const V &a) {  // like the DPP version: every lane gets its 16-lane row's sum, row 1 also row 0's
     uint32_t rs[4] = {0, 0, 0, 0};
     for (int i = 0; i < 64; ++i) rs[i >> 4] += a.v[i];
@@ -193,7 +191,6 @@ struct WaveEmu {
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
     return r;
   }
-  static uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return lds[idx]; }
   static V pow_pair(const uint32_t *xt, const V &m4) {
     EMU_OP();
     V r;
@@ -204,12 +201,6 @@ struct WaveEmu {
     EMU_OP();
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = base[byte_off.v[i] >> 1];
-    return r;
-  }
-  static V lds_u16(const uint16_t *lds, const V &idx, P pred) {
-    EMU_OP();
-    V r;
-    for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
     return r;
   }
   static V gload_u16(const uint16_t *base, const V &idx, P pred) {
