@@ -130,7 +130,9 @@ struct Core {
   static SF_DEV uint32_t draw(Arena &S, const uint8_t *, const Params &p) {  // RN:54-62
     SF_PROF(PH_RNG);
     S.jomle += 1u;
-    const V lnew = W::mul24(S.la, V(S.jomle & 0xffffu)) & 0xffffu;
+    // (not reduced mod 2^16: every consumer of the hot state — the 24-bit multiply by the seed, the table offsets,
+    // store() — takes the low 16 bits itself)
+    const V lnew = W::mul24_su(S.jomle & 0xffffu, S.la);
     const V ln = W::lane();
     S.rl = W::select((ln == 17u) | (ln == 18u), lnew, W::shl1(S.rl));  // rotate left, new value last (+ copy on 18)
     return draw_issue(S, p);  // draw n+1's lookup is now in flight; lane 18's power is draw n's value
@@ -1157,8 +1159,10 @@ struct Core {
     }
     W::gstore(p.por + (size_t)a * (size_t)p.P, ln, S.ppos, W::ltu(ln, (uint32_t)p.P));
     {
-      const P in = W::ltu(ln, 18u), nz = in & ((S.rl & RL_ZERO) == 0u);
-      const V val = W::select(nz, pow3_v(S.xt, S.rl & 0xffffu, nz), V(0u));
+      // a stored generator is always warmed up (k_reset runs _srand's 1024 draws), so no tap is zero; bit 16 of the
+      // hot state is not a flag (see draw())
+      const P in = W::ltu(ln, 18u);
+      const V val = pow3_v(S.xt, S.rl & 0xffffu, in);
       W::gstore(p.rng + (size_t)a * RNG_WORDS, ln, val | (S.rus << 20) | (S.rseed << 24), in);
       W::gstore(p.rng2 + (size_t)a * RNG_WORDS, ln, (S.rl2 & 0x1ffffu) | (S.rseed2 << 24), in);
     }

@@ -75,6 +75,12 @@ struct WaveGfx950 {
   static SF_DEV V lds_u8(const uint8_t *lds, V idx, P pred) { return pred ? (uint32_t)lds[idx] : 0u; }
   static SF_DEV uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return uni((uint32_t)lds[idx]); }
   static SF_DEV V lds_u32(const uint32_t *lds, V idx, P pred) { return pred ? lds[idx] : 0u; }
+  // the same with a wave-uniform first factor, which stays in an SGPR (VOP2 src0)
+  static SF_DEV V mul24_su(uint32_t a, V b) {
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
+    return r;
+  }
   // 3^lo * 3^(256 hi) from the two halves of the power table (1 KiB each, the table 2 KiB-aligned in LDS), for an
   // exponent pre-scaled by 4: the byte offsets are bit fields of m4 OR-ed into the table's address (v_and_or_b32)
   static SF_DEV V pow_pair(const uint32_t *xt, V m4) {

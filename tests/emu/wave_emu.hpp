@@ -171,6 +171,7 @@ struct WaveEmu {
     for (int i = 0; i < 64; ++i) r.v[i] = (a.v[i] & 0xffffffu) * (b.v[i] & 0xffffffu);
     return r;
   }
+  static V mul24_su(uint32_t a, const V &b) { return mul24(V(a), b); }
   static V shl1(const V &a) {
     EMU_OP();
     V r;
