@@ -78,6 +78,30 @@ def cpu_baseline(workload_name, seconds=12.0):
                       % (arenas, workload_name, steps, dt, model, os.cpu_count() or 0)}
 
 
+def other_configs(args, local, torch, config, env):
+    """The same throughput measurement (commands resident, K steps per launch, one GPU) on BASELINE configs[2]: the
+    64x64 map with 32 entities (8 humans + 24 zombies, Timer mode, bullets and throwables active).  The headline is
+    quoted on configs[1]; this is the other reading of the metric's "64x64 map x32 entities"."""
+    w = config.baseline_workload("C3", arenas=args.arenas, device=local)
+    g = env.ArenaBatch(w)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.reset(*w.seeds())
+    steps, warm = 500, 100
+    cmds, _ = config.bench_commands(args.arenas, w.cfg.n_agents, steps + warm)
+    d = torch.from_numpy(cmds).cuda()
+    stride = args.arenas * w.cfg.n_agents
+    g.step_device(d.data_ptr(), warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(warm, warm + steps, args.k_per_launch):
+        g.step_device(d.data_ptr() + s * stride, min(args.k_per_launch, warm + steps - s))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    g.close()
+    return {"configs[2] (C3): %d arenas, 64x64 map, 8 human + 24 zombie + 64 bullet slots, Timer" % args.arenas:
+            {"value": args.arenas * steps / dt, "unit": "env-steps/s", "steps": steps, "warmup": warm}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,6 +330,8 @@ def main():
                              "frac": tf / MFMA_F32_PEAK_TFLOPS, "kernel": "k_gemm (%d launches per forward)" % pol["gemm_launches"],
                              "gemm_ms_per_forward": pol["gemm_ms"], "flop_per_agent_forward": pol["gemm_flop"] / pol["agents"]},
             }
+        if world == 1 and obs_n and args.workload == "C2":
+            out["other_configs"] = other_configs(args, local, torch, config, env)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
