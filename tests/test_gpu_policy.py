@@ -287,3 +287,31 @@ def test_closed_loop_resets_memory_when_a_game_restarts():
     assert restarts >= arenas  # every arena restarted at least once
     hg, ag = pb.get_memory(0)
     np.testing.assert_allclose(hg, h[:, 0], rtol=RTOL, atol=ATOL * 10)
+
+
+def test_large_batch_is_consistent_with_small_batch():
+    """18 000 agents (2.2 GB of observations, conv0 with 4 M rows: byte offsets beyond 2^31, thousands of stream-K
+    tiles) fed 40 distinct observations in rotation give, row for row, what a 40-agent batch gives."""
+    rng = np.random.default_rng(77)
+    params = policy.init_parameters(seed=6)
+    small, big = 40, 18000
+    obs = _obs(rng, small)
+    d_small = _dev(obs)
+    idx = torch.arange(big, device="cuda") % small
+    d_big = d_small[idx].contiguous()
+    out = {}
+    for n, d in ((small, d_small), (big, d_big)):
+        pb = policy.PolicyBatch(params, n)
+        d_probs = torch.zeros((n, 9), dtype=torch.float32, device="cuda")
+        d_value = torch.zeros(n, dtype=torch.float32, device="cuda")
+        for _ in range(2):  # two recurrent steps
+            pb.forward(d.data_ptr(), n, d_probs.data_ptr(), d_value.data_ptr())
+        pb.synchronize()
+        out[n] = (d_probs.cpu().numpy(), d_value.cpu().numpy())
+        pb.close()
+    ps, vs = out[small]
+    pbig, vbig = out[big]
+    ref = np.arange(big) % small
+    # different block shapes / K splits for the two batch sizes: equal up to summation order
+    np.testing.assert_allclose(pbig, ps[ref], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(vbig, vs[ref], rtol=RTOL, atol=ATOL)
