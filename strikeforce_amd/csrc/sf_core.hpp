@@ -533,6 +533,10 @@ struct Core {
     V cell[NB];
     bool any = false;
 #pragma unroll
+    for (int j = 0; j < NB; ++j) any = any || W::ballot((S.ba[j] & BA_ALIVE) != 0u) != 0ull;
+    if (!any) return;  // no bullet in flight: nothing can be absorbed
+    any = false;
+#pragma unroll
     for (int j = 0; j < NB; ++j) {
       const P alive = (S.ba[j] & BA_ALIVE) != 0u;
       cell[j] = S.ba[j] & POS_MASK;
