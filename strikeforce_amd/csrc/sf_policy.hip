@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -337,6 +338,151 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(Gemm g, int KT, int G) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// conv0 on the observation as it really is: 0.8 % non-zero (a 31x31 window of mostly empty cells, 32 features each).
+// One 16-wave workgroup per agent keeps the agent's whole conv0 output (15 x 15 x 160 f32 = 144 KB) in LDS, streams
+// the 123 KB observation once, appends its non-zeros to an LDS list in scan order (block-wide prefix sum: the list
+// order, hence the order of every f32 sum, is deterministic), and applies each (channel, y, x, value) to the <= 4
+// output pixels whose 3x3/stride-2 window contains it: out[oy][ox][n] += value * W[n][c][ky][kx], n on the lanes.
+// An output pixel belongs to the wavefront (oy & 3, ox & 3), so there are no atomics; a wavefront looks at 64 list
+// entries at a time (one per lane: is one of its targets mine?), then walks its own ones in list order, weight rows
+// fetched four targets ahead.  Work is proportional to the non-zeros (~250 per agent, against 65 000 products per
+// output channel in the dense form); any density is handled (the list is flushed when full).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int C0_OUT = 15, C0_ACC = C0_OUT * C0_OUT * HID;  // 36000 floats
+constexpr int C0_T = 1024, C0_WAVES = C0_T / 64;
+constexpr int C0_LCAP = 2048;
+constexpr size_t C0_LDS = (size_t)C0_ACC * 4 + (size_t)C0_LCAP * 8 + 4 * C0_WAVES;
+
+__global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const float *wt, float *act0, int agents) {
+  extern __shared__ __attribute__((aligned(16))) float c0_lds[];
+  float *acc = c0_lds;
+  float *lval = acc + C0_ACC;
+  uint32_t *lkey = reinterpret_cast<uint32_t *>(lval + C0_LCAP);
+  uint32_t *wtot = lkey + C0_LCAP;  // per-wave non-zero counts of the current chunk
+  const int b = blockIdx.x, t = threadIdx.x, w = t >> 6, l = t & 63;
+  if (b >= agents) return;
+  for (int i = t; i < C0_ACC / 4; i += C0_T) reinterpret_cast<f32x4 *>(acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  const int cy = w >> 2, cx = w & 3;  // this wavefront's output pixels: oy % 4 == cy, ox % 4 == cx
+  // the candidate along one axis: input coordinate v lies in the windows of outputs (v - k) / 2 for k == v (mod 2);
+  // at most one of them is congruent to `cls` modulo 4.  Returns the output coordinate or -1, and k.
+  auto axis = [](int v, int cls, int &k) -> int {
+    if (v & 1) {
+      k = 1;
+      const int o = (v - 1) >> 1;
+      return ((o & 3) == cls && o < C0_OUT) ? o : -1;
+    }
+    const int o0 = v >> 1;  // k = 0
+    if ((o0 & 3) == cls) {
+      k = 0;
+      return o0 < C0_OUT ? o0 : -1;
+    }
+    k = 2;
+    const int o2 = o0 - 1;
+    return (o2 >= 0 && (o2 & 3) == cls) ? o2 : -1;
+  };
+  auto process = [&](uint32_t n) {
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+      const uint32_t e = e0 + (uint32_t)l;
+      uint32_t rowo = 0, wro = 0;
+      float val = 0.f;
+      bool mine = false;
+      if (e < n) {
+        const uint32_t key = lkey[e];
+        int ky, kx;
+        const int oy = axis((int)((key >> 9) & 31u), cy, ky), ox = axis((int)((key >> 14) & 31u), cx, kx);
+        mine = oy >= 0 && ox >= 0;
+        rowo = (uint32_t)((oy * C0_OUT + ox) * HID);
+        wro = (uint32_t)(((int)(key & 511u) + ky * 3 + kx) * HID);
+        val = lval[e];
+      }
+      uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+      while (m) {  // four of this wavefront's targets at a time: all weight loads first, then the LDS updates in order
+        uint32_t ro[4], nt = 0;
+        float vv[4], wv[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ro[q] = 0, vv[q] = 0.f;
+          wv[q][0] = wv[q][1] = wv[q][2] = 0.f;
+          if (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1ull;
+            ro[q] = (uint32_t)__builtin_amdgcn_readlane((int)rowo, src);
+            const uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)wro, src);
+            vv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), src));
+            const float *wr = wt + wq;
+            wv[q][0] = wr[l], wv[q][1] = wr[l + 64];
+            if (l < HID - 128) wv[q][2] = wr[l + 128];
+            nt = (uint32_t)q + 1u;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if ((uint32_t)q < nt) {
+            float *row = acc + ro[q];
+            row[l] = fmaf(vv[q], wv[q][0], row[l]);
+            row[l + 64] = fmaf(vv[q], wv[q][1], row[l + 64]);
+            if (l < HID - 128) row[l + 128] = fmaf(vv[q], wv[q][2], row[l + 128]);
+          }
+      }
+    }
+  };
+
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 *src = reinterpret_cast<const f32x2 *>(obs + (size_t)b * OBS_F);
+  constexpr int NV = OBS_F / 2;  // 15376 8-byte pieces: a chunk adds at most 2 * 1024 = C0_LCAP entries
+  uint32_t count = 0;            // list length, the same value in every thread
+  for (int base = 0; base < NV; base += C0_T) {
+    const int i = base + t;
+    f32x2 v = f32x2{0.f, 0.f};
+    if (i < NV) v = __builtin_nontemporal_load(src + i);
+    const uint32_t m = (v.x != 0.f ? 1u : 0u) | (v.y != 0.f ? 2u : 0u);
+    const uint32_t c = (uint32_t)__builtin_popcount(m);
+    uint32_t incl = c;  // inclusive prefix sum over the wavefront, then over the wavefronts through LDS
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+      if (l >= o) incl += up;
+    }
+    if (l == 63) wtot[w] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < C0_WAVES; ++k) {
+      const uint32_t wk = wtot[k];
+      before += k < w ? wk : 0u;
+      total += wk;
+    }
+    if (count + total > (uint32_t)C0_LCAP) {  // (uniform) no room: apply what is listed first
+      process(count);
+      count = 0;
+      __syncthreads();
+    }
+    uint32_t pos = count + before + incl - c;
+    if (m) {
+      const float vv[2] = {v.x, v.y};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if ((m >> j) & 1u) {
+          const uint32_t idx = 2u * (uint32_t)i + (uint32_t)j;  // = ch * 961 + y * 31 + x
+          const uint32_t ch = idx / (uint32_t)(OBS_W * OBS_W), r = idx - ch * (uint32_t)(OBS_W * OBS_W);
+          const uint32_t y = r / (uint32_t)OBS_W, x = r - y * (uint32_t)OBS_W;
+          lkey[pos] = (ch * 9u) | (y << 9) | (x << 14);
+          lval[pos] = vv[j];
+          ++pos;
+        }
+    }
+    count += total;
+    __syncthreads();  // the list is complete and wtot may be rewritten
+  }
+  process(count);
+  __syncthreads();
+  f32x4 *dst = reinterpret_cast<f32x4 *>(act0 + (size_t)b * C0_ACC);
+  for (int i = t; i < C0_ACC / 4; i += C0_T) dst[i] = reinterpret_cast<const f32x4 *>(acc)[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Row kernels: one wavefront per agent, lane l owns elements l, l+64, l+128 (< 160) of a 160-vector.
 // ---------------------------------------------------------------------------------------------------------
 __device__ inline float wave_sum(float v) {
@@ -565,6 +711,8 @@ struct Policy {
   hipStream_t stream = nullptr;
   uint64_t draws = 0;
   // parameters
+  float *conv0_wt = nullptr;  // conv0 weights as [c][ky][kx][n] for k_conv0_sparse
+  bool dense_conv0 = false;   // SF_POLICY_DENSE_CONV0=1: the implicit-GEMM conv0 instead (A/B, tests)
   float *conv_w[4] = {}, *gru_w_ih[2] = {}, *gru_w_hh[2] = {}, *gru_b_ih[2] = {}, *gru_b_hh[2] = {};
   float *comb_w = nullptr, *comb_b = nullptr;
   float *res_w[2][3] = {}, *res_b[2][3] = {}, *head_w[2] = {}, *head_b[2] = {};  // [0] policy, [1] value
@@ -693,6 +841,17 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
   for (int i = 0; i < 4; ++i)
     if (!w->conv_w[i]) SFP_TRY(fail(SF_ERR_ARG, "conv weight is null"));
   SFP_TRY(p->upload(&p->conv_w[0], w->conv_w[0], (size_t)HID * OBS_C * 9));
+  {
+    std::vector<float> tr((size_t)OBS_C * 9 * HID);
+    for (int nn = 0; nn < HID; ++nn)
+      for (int ck = 0; ck < OBS_C * 9; ++ck) tr[(size_t)ck * HID + nn] = w->conv_w[0][(size_t)nn * OBS_C * 9 + ck];
+    SFP_TRY(p->upload(&p->conv0_wt, tr.data(), tr.size()));
+    const char *e = getenv("SF_POLICY_DENSE_CONV0");
+    p->dense_conv0 = e && e[0] == '1';
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv0_sparse), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)C0_LDS) != hipSuccess)
+      SFP_TRY(fail(SF_ERR_DEVICE, "k_conv0_sparse needs 157 KB of LDS per workgroup"));
+  }
   for (int i = 1; i < 4; ++i) {
     // [n][cin][ky][kx] -> [n][ky][kx][cin]: the K-order of an NHWC im2col row
     std::vector<float> perm((size_t)HID * HID * 9);
@@ -758,7 +917,11 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
   const dim3 rg((unsigned)((agents + 3) / 4)), rb(256);
   hipStream_t st = p->stream;
   // GameCNN                                                                    Modules.hpp:66-71
-  if ((rc = p->conv(d_obs, p->conv_w[0], p->act[0], agents, 31, OBS_C, 1))) return rc;
+  if (p->dense_conv0) {
+    if ((rc = p->conv(d_obs, p->conv_w[0], p->act[0], agents, 31, OBS_C, 1))) return rc;
+  } else {
+    hipLaunchKernelGGL(k_conv0_sparse, dim3((unsigned)agents), dim3(C0_T), C0_LDS, st, d_obs, p->conv0_wt, p->act[0], agents);
+  }
   if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, HID, 0))) return rc;
   if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, HID, 0))) return rc;
   if ((rc = p->conv(p->act[2], p->conv_w[3], p->feat, agents, 3, HID, 0))) return rc;
