@@ -351,18 +351,16 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(Gemm g, int KT, int G) {
 constexpr int C0_OUT = 15, C0_ACC = C0_OUT * C0_OUT * HID;  // 36000 floats
 constexpr int C0_T = 1024, C0_WAVES = C0_T / 64;
 constexpr int C0_LCAP = 2048;
-constexpr size_t C0_LDS = (size_t)C0_ACC * 4 + (size_t)C0_LCAP * 8 + 4 * C0_WAVES;
+constexpr size_t C0_LDS = (size_t)C0_ACC * 4 + (size_t)C0_LCAP * 8 + 4 * (2 * 16 * C0_WAVES + 4);
 
 __global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const float *wt, float *act0, int agents) {
   extern __shared__ __attribute__((aligned(16))) float c0_lds[];
   float *acc = c0_lds;
   float *lval = acc + C0_ACC;
   uint32_t *lkey = reinterpret_cast<uint32_t *>(lval + C0_LCAP);
-  uint32_t *wtot = lkey + C0_LCAP;  // per-wave non-zero counts of the current chunk
-  const int b = blockIdx.x, t = threadIdx.x, w = t >> 6, l = t & 63;
-  if (b >= agents) return;
-  for (int i = t; i < C0_ACC / 4; i += C0_T) reinterpret_cast<f32x4 *>(acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
+  uint32_t *cnt = lkey + C0_LCAP;          // [16 pieces][16 waves] non-zero counts
+  uint32_t *offs = cnt + 16 * C0_WAVES;    // their exclusive prefix sums, then the total
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
 
   const int cy = w >> 2, cx = w & 3;  // this wavefront's output pixels: oy % 4 == cy, ox % 4 == cx
   // the candidate along one axis: input coordinate v lies in the windows of outputs (v - k) / 2 for k == v (mod 2);
@@ -429,39 +427,31 @@ __global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const f
     }
   };
 
+  // The workgroup is persistent (one per CU: the output tile fills its LDS) and walks agents b, b + gridDim.x, ...:
+  // the next agent's observation is requested as soon as this one's has been scanned, so its latency passes under
+  // this agent's list processing and write-back, and the write-back's stores drain under the next agent's scan.
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const f32x2 *src = reinterpret_cast<const f32x2 *>(obs + (size_t)b * OBS_F);
   constexpr int NV = OBS_F / 2;  // 15376 8-byte pieces: a chunk adds at most 2 * 1024 = C0_LCAP entries
-  uint32_t count = 0;            // list length, the same value in every thread
-  for (int base = 0; base < NV; base += C0_T) {
-    const int i = base + t;
-    f32x2 v = f32x2{0.f, 0.f};
-    if (i < NV) v = __builtin_nontemporal_load(src + i);
-    const uint32_t m = (v.x != 0.f ? 1u : 0u) | (v.y != 0.f ? 2u : 0u);
-    const uint32_t c = (uint32_t)__builtin_popcount(m);
-    uint32_t incl = c;  // inclusive prefix sum over the wavefront, then over the wavefronts through LDS
+  constexpr int NIT = (NV + C0_T - 1) / C0_T;  // 16 pieces per thread, all requested before the first is looked at
+  f32x2 pre[NIT];
+  auto request = [&](int b) {
+    const f32x2 *src = reinterpret_cast<const f32x2 *>(obs + (size_t)b * OBS_F);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-      if (l >= o) incl += up;
+    for (int k = 0; k < NIT; ++k) {
+      const int i = k * C0_T + t;
+      pre[k] = f32x2{0.f, 0.f};
+      if (i < NV) pre[k] = __builtin_nontemporal_load(src + i);
     }
-    if (l == 63) wtot[w] = incl;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < C0_WAVES; ++k) {
-      const uint32_t wk = wtot[k];
-      before += k < w ? wk : 0u;
-      total += wk;
-    }
-    if (count + total > (uint32_t)C0_LCAP) {  // (uniform) no room: apply what is listed first
-      process(count);
-      count = 0;
-      __syncthreads();
-    }
-    uint32_t pos = count + before + incl - c;
+  };
+  if ((int)blockIdx.x < agents) request((int)blockIdx.x);
+  for (int b = (int)blockIdx.x; b < agents; b += (int)gridDim.x) {
+  for (int i = t; i < C0_ACC / 4; i += C0_T) reinterpret_cast<f32x4 *>(acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  uint32_t count = 0;  // list length, the same value in every thread
+  auto append = [&](int k, uint32_t m, uint32_t pos) {
     if (m) {
-      const float vv[2] = {v.x, v.y};
+      const int i = k * C0_T + t;
+      const float vv[2] = {pre[k].x, pre[k].y};
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         if ((m >> j) & 1u) {
@@ -473,13 +463,61 @@ __global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const f
           ++pos;
         }
     }
-    count += total;
-    __syncthreads();  // the list is complete and wtot may be rewritten
+  };
+  // Where does every non-zero go?  Wave-level: two ballots per piece (x non-zero, y non-zero) give a lane's offset
+  // (mbcnt) and the wave's count (popcount) without any shuffle; the 16 pieces x 16 waves counts go to LDS, wave 0
+  // turns them into offsets in (piece, wave) order = scan order, and if everything fits the list (it does, unless the
+  // input is not an observation) all entries are written in one go.  Three barriers instead of two per piece.
+  uint32_t lanepre[NIT], mpack = 0;
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const uint32_t m = (pre[k].x != 0.f ? 1u : 0u) | (pre[k].y != 0.f ? 2u : 0u);
+    const uint64_t b0 = __builtin_amdgcn_ballot_w64((m & 1u) != 0u), b1 = __builtin_amdgcn_ballot_w64((m & 2u) != 0u);
+    lanepre[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                 __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+    if (l == k) cnt[k * C0_WAVES + w] = (uint32_t)(__builtin_popcountll(b0) + __builtin_popcountll(b1));
+    mpack |= m << (2 * k);
   }
-  process(count);
   __syncthreads();
+  if (w == 0) {  // exclusive prefix of the 256 counts, four per lane
+    uint32_t c4[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c4[j] = cnt[4 * l + j], sum += c4[j];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+      if (l >= o) incl += up;
+    }
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offs[4 * l + j] = run, run += c4[j];
+    if (l == 63) offs[NIT * C0_WAVES] = incl;
+  }
+  __syncthreads();
+  // write and apply the list; an observation fits in one batch, anything denser goes in as many as it takes
+  // (pieces [ks, ke) at a time, ke the furthest piece boundary that still fits: a single piece always does)
+  int ks = 0;
+  do {
+    const uint32_t base = offs[ks * C0_WAVES];
+    int ke = ks + 1;
+#pragma unroll
+    for (int kk = 2; kk <= NIT; ++kk)
+      if (kk > ks + 1 && offs[kk * C0_WAVES] - base <= (uint32_t)C0_LCAP) ke = kk;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      if (k >= ks && k < ke) append(k, (mpack >> (2 * k)) & 3u, offs[k * C0_WAVES + w] - base + lanepre[k]);
+    count = offs[ke * C0_WAVES] - base;
+    __syncthreads();
+    if (ke == NIT && b + (int)gridDim.x < agents) request(b + (int)gridDim.x);  // `pre` is free: fetch the next agent
+    process(count);
+    __syncthreads();
+    ks = ke;
+  } while (ks < NIT);
   f32x4 *dst = reinterpret_cast<f32x4 *>(act0 + (size_t)b * C0_ACC);
   for (int i = t; i < C0_ACC / 4; i += C0_T) dst[i] = reinterpret_cast<const f32x4 *>(acc)[i];
+  __syncthreads();  // the tile has been read out before the next agent zeroes it
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -920,7 +958,7 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
   if (p->dense_conv0) {
     if ((rc = p->conv(d_obs, p->conv_w[0], p->act[0], agents, 31, OBS_C, 1))) return rc;
   } else {
-    hipLaunchKernelGGL(k_conv0_sparse, dim3((unsigned)agents), dim3(C0_T), C0_LDS, st, d_obs, p->conv0_wt, p->act[0], agents);
+    hipLaunchKernelGGL(k_conv0_sparse, dim3((unsigned)(agents < p->sk_blocks / 2 ? agents : p->sk_blocks / 2)), dim3(C0_T), C0_LDS, st, d_obs, p->conv0_wt, p->act[0], agents);
   }
   if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, HID, 0))) return rc;
   if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, HID, 0))) return rc;
