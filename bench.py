@@ -323,8 +323,9 @@ def main():
         if pol:
             tf = pol["gemm_flop"] / (pol["gemm_ms"] / 1e3) / 1e12
             out["policy"] = {
-                "what": "per rank: observe -> bot-0.5 network (f32 MFMA, random-init weights) -> sample -> K=1 step, "
-                        "all on device, %d steps" % pol["steps"],
+                "what": "per rank: observe -> bot-0.5 network (f32, random-init weights; conv0 on the observation's non-zeros, "
+                        "conv1..3 and the dense layers on the f32 MFMA: the roofline below is over those matrix launches) "
+                        "-> sample -> K=1 step, all on device, %d steps" % pol["steps"],
                 "agent_steps_per_s": world * pol["agents"] / (pol["loop_ms"] / 1e3), "ms_per_step": pol["loop_ms"],
                 "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf / MFMA_F32_PEAK_TFLOPS, "kernel": "k_gemm (%d launches per forward)" % pol["gemm_launches"],
