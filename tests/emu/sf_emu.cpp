@@ -136,13 +136,16 @@ struct sfe_env {
 };
 
 extern "C" {
-// op profile of the device source: out[0] = all vector ops, out[1 + ph] = ops in phase ph; clears the counters
+// op profile of the device source: out[0] = all vector ops, out[1 + ph] = vector ops in phase ph, out[1 + PH_COUNT + ph]
+// = wave-uniform accesses (readlane / ballot / setlane / uniform LDS) in phase ph; clears the counters (out: 32 words)
 int sfe_profile(uint64_t *out) {
   sf::EmuProf &q = sf::emu_prof();
   q.by[q.phase] += q.ops - q.mark, q.mark = q.ops;
   out[0] = q.ops;
+  q.sby[q.phase] += q.sops - q.smark, q.smark = q.sops;
   for (int i = 0; i < sf::PH_COUNT; ++i) out[1 + i] = q.by[i], q.by[i] = 0;
-  q.ops = q.mark = 0;
+  for (int i = 0; i < sf::PH_COUNT; ++i) out[1 + sf::PH_COUNT + i] = q.sby[i], q.sby[i] = 0;
+  q.ops = q.mark = 0, q.sops = q.smark = 0;
   return sf::PH_COUNT;
 }
 sfe_env *sfe_create(const sf_config *cfg) {

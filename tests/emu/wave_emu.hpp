@@ -17,6 +17,7 @@ namespace sf {
 enum { PH_OTHER, PH_RNG, PH_ZOMBIE, PH_PORTAL, PH_HUMAN, PH_TMP, PH_HITS, PH_BULL, PH_TOP, PH_WARM, PH_COUNT };
 struct EmuProf {
   uint64_t ops = 0, mark = 0, by[PH_COUNT] = {};
+  uint64_t sops = 0, smark = 0, sby[PH_COUNT] = {};  // wave-uniform accesses (readlane, ballot, setlane, uniform LDS)
   int phase = PH_OTHER;
 };
 inline EmuProf &emu_prof() {
@@ -28,16 +29,19 @@ struct EmuProfScope {
   explicit EmuProfScope(int ph) {
     EmuProf &q = emu_prof();
     q.by[q.phase] += q.ops - q.mark, q.mark = q.ops;
+    q.sby[q.phase] += q.sops - q.smark, q.smark = q.sops;
     prev = q.phase, q.phase = ph;
   }
   ~EmuProfScope() {
     EmuProf &q = emu_prof();
     q.by[q.phase] += q.ops - q.mark, q.mark = q.ops;
+    q.sby[q.phase] += q.sops - q.smark, q.smark = q.sops;
     q.phase = prev;
   }
 };
 #define SF_PROF(ph) ::sf::EmuProfScope sf_prof_scope_(::sf::ph)
 #define EMU_OP() (++::sf::emu_prof().ops)
+#define EMU_SOP() (++::sf::emu_prof().sops)
 
 struct EmuP {
   uint64_t m;
@@ -114,11 +118,20 @@ struct WaveEmu {
     for (int i = 0; i < 64; ++i) r.v[i] = (uint32_t)i;
     return r;
   }
-  static uint64_t ballot(P p) { return p.m; }
+  static uint64_t ballot(P p) {
+    EMU_SOP();
+    return p.m;
+  }
   static int ctz64(uint64_t m) { return __builtin_ctzll(m); }
   static int clz64(uint64_t m) { return __builtin_clzll(m); }
-  static uint32_t readlane(const V &v, uint32_t idx) { return v.v[idx & 63u]; }
-  static void setlane(V &v, uint32_t idx, uint32_t val) { v.v[idx & 63u] = val; }
+  static uint32_t readlane(const V &v, uint32_t idx) {
+    EMU_SOP();
+    return v.v[idx & 63u];
+  }
+  static void setlane(V &v, uint32_t idx, uint32_t val) {
+    EMU_SOP();
+    v.v[idx & 63u] = val;
+  }
   static V select(P p, const V &a, const V &b) {
     EMU_OP();
     V r;
@@ -185,7 +198,10 @@ struct WaveEmu {
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
     return r;
   }
-  static uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return lds[idx]; }
+  static uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) {
+    EMU_SOP();
+    return lds[idx];
+  }
   static V lds_u32(const uint32_t *lds, const V &idx, P pred) {
     EMU_OP();
     V r;
