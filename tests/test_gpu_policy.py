@@ -315,3 +315,36 @@ def test_large_batch_is_consistent_with_small_batch():
     # different block shapes / K splits for the two batch sizes: equal up to summation order
     np.testing.assert_allclose(pbig, ps[ref], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(vbig, vs[ref], rtol=RTOL, atol=ATOL)
+
+
+def test_closed_loop_multi_agent_arenas():
+    """BASELINE configs[4] (Battle Royale, 8 commanded humans per arena): the policy's agent index is
+    arena * n_agents + agent, the order of the observation buffer and of the command array; shadowed by the oracle."""
+    arenas, steps = 2, 6
+    w = config.baseline_workload("C5", arenas=arenas)
+    o, g = Oracle(w), env.ArenaBatch(w)
+    tb, sr = w.seeds()
+    o.reset(tb, sr), g.reset(tb, sr)
+    B = arenas * w.cfg.n_agents
+    assert w.cfg.n_agents == 8
+    params = policy.init_parameters(seed=12)
+    pb = policy.PolicyBatch(params, B)
+    d_obs = torch.zeros((B, 32, 31, 31), dtype=torch.float32, device="cuda")
+    d_probs = torch.zeros((B, 9), dtype=torch.float32, device="cuda")
+    d_value = torch.zeros(B, dtype=torch.float32, device="cuda")
+    d_cmd = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    d_act = torch.zeros(B, dtype=torch.int32, device="cuda")
+    h = np.zeros((2, B, 160), dtype=np.float32)
+    a = np.eye(9, dtype=np.float32)[[0] * B]
+    for t in range(steps):
+        g.observe_device(d_obs.data_ptr())
+        pb.forward(d_obs.data_ptr(), B, d_probs.data_ptr(), d_value.data_ptr())
+        pb.act(d_probs.data_ptr(), B, d_cmd.data_ptr(), seed=3, d_action_ptr=d_act.data_ptr())
+        g.step_device(d_cmd.data_ptr(), 1)
+        g.synchronize(), pb.synchronize()
+        probs, value, h = policy_ref.forward_batched(params, o.observe().reshape(B, 32, 31, 31), h, a)
+        np.testing.assert_allclose(d_probs.cpu().numpy(), probs, rtol=RTOL, atol=ATOL)
+        a = np.eye(9, dtype=np.float32)[d_act.cpu().numpy()]
+        o.step(d_cmd.cpu().numpy())
+        assert (o.digest() == g.digest()).all()
+    assert np.abs(probs[0] - probs[1]).max() > 1e-4  # different agents see different windows
