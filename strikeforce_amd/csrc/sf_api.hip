@@ -80,11 +80,6 @@ static __device__ __forceinline__ int obs_class_of(uint32_t fl) {
   }
   return -1;
 }
-static __device__ __forceinline__ uint32_t obs_class_flags(int c) {
-  return c == 0 ? SF_CELL_WALL : c == 1 ? SF_CELL_PIN_UP : c == 2 ? SF_CELL_PIN_DN : c == 3 ? SF_CELL_POUT
-       : (uint32_t)SF_CELL_CHEST | ((uint32_t)(c - 4) << SF_CELL_CONS_SHIFT);
-}
-
 __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ent[];  // [13][H] humans, [3][Z] zombies, [4][B] bullets
   __shared__ float rec[OBS_REC_MAX][SF_OBS_CHANNELS];
@@ -96,6 +91,8 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   __shared__ float list_val[OBS_LIST_MAX];
   __shared__ uint32_t nzmap[OBS_W2];  // one bit per output float: non-zero (30752 bits)
   __shared__ uint32_t cmask[OBS_CLASS_RECS];  // non-zero channels of each class record
+  __shared__ uint16_t work[OBS_REC_MAX];      // window cell of record r (r >= OBS_CLASS_RECS)
+  __shared__ float t_in[16], t_out[16];       // Tables::obs_in / obs_out (obs_in[0] == 1.0)
   __shared__ uint32_t list_n, rec_n, spill_n;
   const int a = (int)blockIdx.x / p.n_agents, g = (int)blockIdx.x % p.n_agents;
   const int tid = (int)threadIdx.x;
@@ -117,6 +114,8 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   const int pteam = (int)((hf >> HF_TEAM_SH) & 255u);
   const int r0 = pos_r(center) - SF_OBS_WINDOW / 2, c0 = pos_c(center) - SF_OBS_WINDOW / 2, f0 = pos_f(center);
   if (tid == 0) list_n = 0u, rec_n = (uint32_t)OBS_CLASS_RECS, spill_n = 0u;
+  if (tid < 16) t_in[tid] = gptr(p.tab)->obs_in[tid], t_out[tid] = gptr(p.tab)->obs_out[tid];
+  const int t_n = gptr(p.tab)->obs_n;
   for (int w = tid; w < OBS_W2; w += OBS_THREADS) {
     const int i = r0 + w / SF_OBS_WINDOW, j = c0 + w % SF_OBS_WINDOW;
     uint32_t fl = 0;
@@ -153,34 +152,48 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   // items 0..7 are the shared class records (a pseudo-cell with that class's flag byte and nothing on it), items
   // 8.. are the window cells; one instantiation of obs_cell_emit serves both
   const Tables &tab = *p.tab;
-  for (int item = tid; item < OBS_CLASS_RECS + OBS_W2; item += OBS_THREADS) {
-    const bool is_class = item < OBS_CLASS_RECS;
-    const int w = item - OBS_CLASS_RECS;
-    const uint32_t fl = is_class ? obs_class_flags(item) : (uint32_t)wfl[w];
-    const uint32_t oc = is_class ? 0u : occ[w];
+  // 3a: every window cell is classified (empty / plain static cell -> shared class record / needs its own record);
+  // the few cells that need a record are queued, so that the heavy feature code below runs once, densely, on
+  // consecutive threads instead of once per wavefront per sweep of the window
+  for (int w = tid; w < OBS_W2; w += OBS_THREADS) {
+    const uint32_t fl = (uint32_t)wfl[w], oc = occ[w];
     if (fl == 0u && oc == 0u) continue;  // '.' with nothing on it
-    uint32_t r;
-    if (is_class) {
-      r = (uint32_t)item;
-    } else {
-      const int cls = oc == 0u ? obs_class_of(fl) : -1;
-      if (cls >= 0) {  // plain static cell: shared record, its non-zero bits are set after the barrier
-        slot[w] = (uint8_t)cls;
-        continue;
-      }
-      r = atomicAdd(&rec_n, 1u);
-      if (r >= (uint32_t)OBS_REC_MAX) {
-        atomicAdd(&spill_n, 1u);  // more non-empty cells than records: written after the stream, see below
-        continue;
-      }
-      slot[w] = (uint8_t)r;
+    const int cls = oc == 0u ? obs_class_of(fl) : -1;
+    if (cls >= 0) {  // plain static cell: shared record, its non-zero bits are set after the barrier
+      slot[w] = (uint8_t)cls;
+      continue;
     }
+    const uint32_t r = atomicAdd(&rec_n, 1u);
+    if (r >= (uint32_t)OBS_REC_MAX) {
+      atomicAdd(&spill_n, 1u);  // more non-empty cells than records: written after the stream, see below
+      continue;
+    }
+    slot[w] = (uint8_t)r;
+    work[r] = (uint16_t)w;
+  }
+  lds_barrier();
+  // 3b: records 0..7 are the shared class records, finished on the host (Tables::class_rec); records 8.. belong to
+  // the queued window cells and are built here
+  rec[tid >> 5][tid & 31] = gptr(p.tab)->class_rec[tid >> 5][tid & 31];  // 8 x 32 = OBS_THREADS values
+  if (tid < OBS_CLASS_RECS) cmask[tid] = gptr(p.tab)->class_mask[tid];
+  const int n_items = (int)(rec_n < (uint32_t)OBS_REC_MAX ? rec_n : (uint32_t)OBS_REC_MAX);
+  for (int item = OBS_CLASS_RECS + tid; item < n_items; item += OBS_THREADS) {
+    const int w = (int)work[item];
+    const uint32_t fl = (uint32_t)wfl[w], oc = occ[w];
+    const uint32_t r = (uint32_t)item;
 #pragma unroll
     for (int k = 0; k < SF_OBS_CHANNELS; ++k) rec[r][k] = 0.f;
     uint32_t mask = 0u;
-    obs_cell_emit(v, fl, is_class ? 0 : wdmg[w], oc, pteam, [&](int k, float x) {
-      float y;
-      const bool fast = obs_map_fast(tab, x, y);
+    obs_cell_emit(v, fl, wdmg[w], oc, pteam, [&](int k, float x) {
+      // obs_map_fast() on the LDS copy of the constant table; 1.0 (a set flag) is most of what is emitted
+      float y = 0.f;
+      bool fast = x == 0.f;
+      if (x == 1.f) {
+        y = t_out[0], fast = true;
+      } else if (!fast) {
+        for (int i = 1; i < t_n; ++i)
+          if (x == t_in[i]) y = t_out[i], fast = true;
+      }
       if (fast && y == 0.f) return;
       mask |= 1u << k;
       if (fast) {
@@ -193,13 +206,9 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
           rec[r][k] = obs_map(x);
       }
     });
-    if (is_class) {
-      cmask[item] = mask;
-    } else {
-      for (uint32_t m = mask; m; m &= m - 1u) {
-        const uint32_t bit = (uint32_t)__builtin_ctz(m) * OBS_W2 + (uint32_t)w;
-        atomicOr(&nzmap[bit >> 5], 1u << (bit & 31u));
-      }
+    for (uint32_t m = mask; m; m &= m - 1u) {
+      const uint32_t bit = (uint32_t)__builtin_ctz(m) * OBS_W2 + (uint32_t)w;
+      atomicOr(&nzmap[bit >> 5], 1u << (bit & 31u));
     }
   }
   lds_barrier();

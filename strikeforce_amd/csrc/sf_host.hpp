@@ -15,6 +15,7 @@
 
 #include "../../include/strikeforce.h"
 #include "sf_types.hpp"
+#include "sf_obs.hpp"
 
 namespace sf {
 
@@ -222,6 +223,20 @@ struct Env {
       for (int i = 0; i < n; ++i) {
         tab.obs_in[i] = in[i];
         tab.obs_out[i] = (float)pow((double)(fabsf(in[i]) / 10), 0.2);  // Custom.hpp:157, host libm
+      }
+      // the records of plain static cells, through the same describe() code the kernel runs for occupied cells
+      Params hp = p;
+      hp.tab = &tab;
+      const ObsView hv(hp, 0);
+      for (int c = 0; c < 8; ++c) {
+        tab.class_mask[c] = 0u;
+        for (int k = 0; k < 32; ++k) tab.class_rec[c][k] = 0.f;
+        obs_cell_emit(hv, obs_class_flags(c), 0, 0u, 0, [&](int k, float x) {
+          float y;
+          if (!obs_map_fast(tab, x, y)) y = obs_map(x);
+          tab.class_rec[c][k] = y;
+          if (y != 0.f) tab.class_mask[c] |= 1u << k;
+        });
       }
     }
     // static map: gameplay.hpp:1249-1274

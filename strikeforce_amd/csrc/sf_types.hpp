@@ -78,6 +78,10 @@ struct Tables {
   int32_t teams[16];         // BATTLE mode team of agent i
   int32_t obs_n;             // observation fast map: obs_out[i] = obs_map(obs_in[i]), filled on the host
   float obs_in[16], obs_out[16];
+  // the finished 32-feature records of the eight kinds of plain static cell ('#', '^', 'v', 'O', chest types 0-3 with
+  // nothing on them) and which of their features are non-zero: the same for every arena and every call
+  float class_rec[8][32];
+  uint32_t class_mask[8];
 };
 
 // ---- everything a kernel needs -----------------------------------------------------------------------
