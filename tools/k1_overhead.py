@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from strikeforce_amd import config, env
 w = config.baseline_workload("C2", arenas=4096, auto_reset=0)
