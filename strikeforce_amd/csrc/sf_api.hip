@@ -8,6 +8,8 @@
 // There is no CPU path: without a HIP device every entry point fails with SF_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include <new>
 #include <utility>
 #include <vector>
@@ -93,6 +95,12 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   __shared__ uint32_t cmask[OBS_CLASS_RECS];  // non-zero channels of each class record
   __shared__ uint16_t work[OBS_REC_MAX];      // window cell of record r (r >= OBS_CLASS_RECS)
   __shared__ float t_in[16], t_out[16];       // Tables::obs_in / obs_out (obs_in[0] == 1.0)
+  // the leading part of Tables that obs_cell_emit reads through ObsView::tab (der[2], cons_items): an LDS copy, so
+  // that the one lane describing a human cell does not walk four dependent L2 loads in get_damage_effect
+  constexpr int TAB_WORDS = (int)((sizeof(Derived) * 2 + sizeof(int32_t) * 12) / 4);
+  __shared__ uint32_t tab_lds[TAB_WORDS];
+  static_assert(offsetof(Tables, der) == 0 && offsetof(Tables, cons_items) == sizeof(Derived) * 2,
+                "obs_cell_emit's tables must lead Tables");
   __shared__ uint32_t list_n, rec_n, spill_n;
   const int a = (int)blockIdx.x / p.n_agents, g = (int)blockIdx.x % p.n_agents;
   const int tid = (int)threadIdx.x;
@@ -116,6 +124,7 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   if (tid == 0) list_n = 0u, rec_n = (uint32_t)OBS_CLASS_RECS, spill_n = 0u;
   if (tid < 16) t_in[tid] = gptr(p.tab)->obs_in[tid], t_out[tid] = gptr(p.tab)->obs_out[tid];
   const int t_n = gptr(p.tab)->obs_n;
+  for (int i = tid; i < TAB_WORDS; i += OBS_THREADS) tab_lds[i] = reinterpret_cast<const SF_GLOBAL uint32_t *>(gptr(p.tab))[i];
   for (int w = tid; w < OBS_W2; w += OBS_THREADS) {
     const int i = r0 + w / SF_OBS_WINDOW, j = c0 + w % SF_OBS_WINDOW;
     uint32_t fl = 0;
@@ -131,6 +140,7 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   // ---- pass 2 ----------------------------------------------------------------------------------------------
   ObsView v(p, 0);  // the LDS copy: one arena, [field][slot]
   v.hum_ = ent, v.zom_ = ent + nh, v.bul_ = ent + nh + nz, v.A = 1;
+  v.tab = reinterpret_cast<const Tables *>(tab_lds);
   for (int e = tid; e < p.H + p.Z + p.B; e += OBS_THREADS) {
     int s = -1;
     uint32_t bits = 0;
