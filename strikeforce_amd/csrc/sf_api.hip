@@ -193,6 +193,9 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
     const uint32_t r = (uint32_t)item;
 #pragma unroll
     for (int k = 0; k < SF_OBS_CHANNELS; ++k) rec[r][k] = 0.f;
+    float ti[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ti[i] = i < t_n ? t_in[i] : __builtin_nanf("");
     uint32_t mask = 0u;
     obs_cell_emit(v, fl, wdmg[w], oc, pteam, [&](int k, float x) {
       // obs_map_fast() on the LDS copy of the constant table; 1.0 (a set flag) is most of what is emitted
@@ -201,8 +204,11 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
       if (x == 1.f) {
         y = t_out[0], fast = true;
       } else if (!fast) {
-        for (int i = 1; i < t_n; ++i)
-          if (x == t_in[i]) y = t_out[i], fast = true;
+        int hit = -1;  // the table's inputs are in registers (ti): a value that is not in it costs 15 compares, no LDS trip
+#pragma unroll
+        for (int i = 1; i < 16; ++i)
+          if (x == ti[i]) hit = i;
+        if (hit >= 0) y = t_out[hit], fast = true;
       }
       if (fast && y == 0.f) return;
       mask |= 1u << k;
