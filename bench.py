@@ -209,10 +209,10 @@ def main():
 
     # the interactive loop an RL learner runs: one launch per step (K = 1) + the observation of every agent
     obs_n = 0 if args.no_interactive else 40
-    loop_ms = obs_ms = k1_ms = host_ms = 0.0
+    loop_ms = obs_ms = k1_ms = host_ms = loop_delta_ms = 0.0
     if obs_n:
         d_obs = torch.empty(args.arenas * cfg.n_agents * 30752, dtype=torch.float32, device="cuda")
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         g.observe_device(d_obs.data_ptr())
         torch.cuda.synchronize()
         ev[0].record()
@@ -226,10 +226,18 @@ def main():
         for s in range(obs_n):
             g.step_device(d_cmds.data_ptr() + (s % total) * stride, 1)
         ev[3].record()
+        # the same loop with sf_observe_device_delta: one persistent observation buffer, only the changes are written
+        g.observe_device_delta(d_obs.data_ptr())
+        ev[4].record()
+        for s in range(obs_n):
+            g.step_device(d_cmds.data_ptr() + (s % total) * stride, 1)
+            g.observe_device_delta(d_obs.data_ptr())
+        ev[5].record()
         torch.cuda.synchronize()
         loop_ms = ev[0].elapsed_time(ev[1]) / obs_n
         obs_ms = ev[1].elapsed_time(ev[2]) / obs_n
         k1_ms = ev[2].elapsed_time(ev[3]) / obs_n
+        loop_delta_ms = ev[4].elapsed_time(ev[5]) / obs_n
         # PCIe-inclusive: sf_step() with a host command array (H2D copy of arenas*agents bytes + K=1 launch)
         t1 = time.perf_counter()
         for s in range(obs_n):
@@ -254,7 +262,7 @@ def main():
 
         def closed_loop(n):
             for _ in range(n):
-                g.observe_device(d_obs.data_ptr())
+                g.observe_device_delta(d_obs.data_ptr())
                 pb.forward(d_obs.data_ptr(), agents, d_probs.data_ptr(), d_value.data_ptr())
                 pb.act(d_probs.data_ptr(), agents, d_pcmd.data_ptr(), seed=rank)
                 g.step_device(d_pcmd.data_ptr(), 1)
@@ -315,6 +323,10 @@ def main():
               "what": "per rank: K=1 launch per step + sf_observe_device for every agent, %d steps" % obs_n,
               "env_steps_per_s": world * args.arenas / (loop_ms / 1e3),
               "ms_per_step": loop_ms, "k_step_K1_ms": k1_ms, "k_observe_ms": obs_ms,
+              "delta_observation": {"what": "same loop with sf_observe_device_delta (one persistent buffer, only changed "
+                                            "floats written; buffer bit-identical to the plain call's)",
+                                    "env_steps_per_s": world * args.arenas / (loop_delta_ms / 1e3),
+                                    "ms_per_step": loop_delta_ms},
             "sf_step_host_cmd_ms": host_ms,
               "k_observe_roofline": {"bound": "hbm", "achieved": obs_bytes / (obs_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": obs_bytes / (obs_ms / 1e3) / 1e9 / HBM_PEAK_GBS,

@@ -28,7 +28,7 @@ d_cmd = torch.zeros(agents, dtype=torch.uint8, device="cuda")
 d_new = torch.zeros(agents, dtype=torch.uint8, device="cuda")
 t0 = time.perf_counter()
 for t in range(steps):
-    sim.observe_device(d_obs.data_ptr())                                            # gameplay::bot()'s encoding
+    sim.observe_device_delta(d_obs.data_ptr())                                      # gameplay::bot()'s encoding (changes only)
     net.forward(d_obs.data_ptr(), agents, d_probs.data_ptr(), d_value.data_ptr())   # AgentModel::forward
     net.act(d_probs.data_ptr(), agents, d_cmd.data_ptr(), seed=1234)                # Agent::predict's sampling + update
     sim.step_device(d_cmd.data_ptr(), 1)                                            # one tick of every arena

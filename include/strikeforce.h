@@ -179,6 +179,12 @@ int sf_step_device(sf_env *env, const uint8_t *d_cmd, int32_t k);
  * (arena, agent): out[arenas][n_agents][32][31][31] float32. */
 int sf_observe(sf_env *env, float *out_host);
 int sf_observe_device(sf_env *env, float *d_out);
+/* The same observation for a caller that keeps ONE device buffer per env and never writes to it: only the floats
+ * that were non-zero after the previous call on this buffer, or are non-zero now, are written (an observation is
+ * about 1 % non-zero, so this is a small fraction of the 123 KB per agent).  The first call on a buffer, a call with
+ * another pointer, or one after a plain observe call on it writes everything.  The buffer ends up bit-identical
+ * to what the plain call would have written. */
+int sf_observe_device_delta(sf_env *env, float *d_out);
 
 /* Per (arena, agent) 8 x int32: kills, teams_kills, loot, damage, effect, Hp, frames, outcome
  * (gameplay.hpp:461,588-593,625-629; Character.hpp:294).  Latched at episode end. */

@@ -82,7 +82,10 @@ static __device__ __forceinline__ int obs_class_of(uint32_t fl) {
   }
   return -1;
 }
-__global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out) {
+// mode 0: plain.  mode 1: plain + record which floats are non-zero in nzprev.  mode 2 (sf_observe_device_delta): the
+// buffer still holds what the previous call left, nzprev says which floats of it are non-zero: only 16-byte pieces
+// with an old or a new non-zero are written.
+__global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out, uint32_t *nzprev, int mode) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ent[];  // [13][H] humans, [3][Z] zombies, [4][B] bullets
   __shared__ float rec[OBS_REC_MAX][SF_OBS_CHANNELS];
   __shared__ uint32_t occ[OBS_W2];
@@ -92,6 +95,8 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   __shared__ uint32_t list_idx[OBS_LIST_MAX];
   __shared__ float list_val[OBS_LIST_MAX];
   __shared__ uint32_t nzmap[OBS_W2];  // one bit per output float: non-zero (30752 bits)
+  uint32_t *ormap = reinterpret_cast<uint32_t *>(wdmg);  // delta mode, pass 4: the previous call's map (wdmg is dead
+                                                          // by then unless a spill follows, and a spill disables delta)
   __shared__ uint32_t cmask[OBS_CLASS_RECS];  // non-zero channels of each class record
   __shared__ uint16_t work[OBS_REC_MAX];      // window cell of record r (r >= OBS_CLASS_RECS)
   __shared__ float t_in[16], t_out[16];       // Tables::obs_in / obs_out (obs_in[0] == 1.0)
@@ -110,8 +115,15 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   // ---- prologue --------------------------------------------------------------------------------------------
   const uint32_t hf = gptr(p.hum)[((size_t)HW_FLAGS * p.A + a) * p.H + g];
   const uint32_t center = gptr(p.hum)[((size_t)HW_POS * p.A + a) * p.H + g];
+  SF_GLOBAL uint32_t *old = nzprev ? gptr(nzprev) + (size_t)blockIdx.x * OBS_W2 : nullptr;
   if ((hf & (HF_ALIVE | HF_CTRL)) != (HF_ALIVE | HF_CTRL)) {  // no observer: all zero (uniform over the workgroup)
-    for (int i = tid; i < SF_OBS_FLOATS / 4; i += OBS_THREADS) __builtin_nontemporal_store((f32x4)(0.f), &o4[i]);
+    for (int i = tid; i < SF_OBS_FLOATS / 4; i += OBS_THREADS)
+      if (mode != 2 || ((old[(4u * (uint32_t)i) >> 5] >> ((4u * (uint32_t)i) & 31u)) & 15u))
+        __builtin_nontemporal_store((f32x4)(0.f), &o4[i]);
+    if (mode) {
+      __syncthreads();  // every old word has been read
+      for (int w = tid; w < OBS_W2; w += OBS_THREADS) old[w] = 0u;
+    }
     return;
   }
   const int nh = HW_WORDS * p.H, nz = ZW_WORDS * p.Z, nb = BW_WORDS * p.B;
@@ -243,10 +255,16 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   }
   lds_barrier();
   // ---- pass 4 ----------------------------------------------------------------------------------------------
+  const bool delta = mode == 2 && spill_n == 0u;  // (a window crowded beyond the records is written in full)
+  if (delta) {  // the old map next to the new one in LDS (over wdmg): one coalesced read instead of one per piece
+    for (int w = tid; w < OBS_W2; w += OBS_THREADS) ormap[w] = old[w];
+    lds_barrier();
+  }
 #pragma unroll 2
   for (int i = tid; i < SF_OBS_FLOATS / 4; i += OBS_THREADS) {
     const uint32_t idx = 4u * (uint32_t)i;
     const uint32_t nib = (nzmap[idx >> 5] >> (idx & 31u)) & 15u;  // idx is a multiple of 4: a nibble never straddles
+    if (delta && !(nib | ((ormap[idx >> 5] >> (idx & 31u)) & 15u))) continue;  // was zero, stays zero: not written
     f32x4 val = (f32x4)(0.f);
     if (nib) {  // ~5 % of the 16-B chunks
       uint32_t k = idx / (uint32_t)OBS_W2, w = idx - k * (uint32_t)OBS_W2;
@@ -258,6 +276,8 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
     }
     __builtin_nontemporal_store(val, &o4[i]);  // streamed once, never re-read by this kernel
   }
+  if (mode)  // what this buffer now holds; after a spill, "anything": the next delta call rewrites it all
+    for (int w = tid; w < OBS_W2; w += OBS_THREADS) old[w] = spill_n ? 0xffffffffu : nzmap[w];
   if (spill_n) {  // a window crowded beyond OBS_REC_MAX cells (never in the BASELINE configs): direct, slower
     __syncthreads();  // the streamed zeros of those cells are complete before they are overwritten
     for (int w = tid; w < OBS_W2; w += OBS_THREADS) {
@@ -401,10 +421,10 @@ struct HipRT {
     SF_HIP(hipGetLastError());
     return SF_OK;
   }
-  int launch_observe(const Params &p, int, float *out) {
+  int launch_observe(const Params &p, int, float *out, uint32_t *nzprev, int mode) {
     SF_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(k_observe, dim3((unsigned)(p.A * p.n_agents)), dim3(OBS_THREADS),
-                       (size_t)(HW_WORDS * p.H + ZW_WORDS * p.Z + BW_WORDS * p.B) * sizeof(uint32_t), stream, p, out);
+                       (size_t)(HW_WORDS * p.H + ZW_WORDS * p.Z + BW_WORDS * p.B) * sizeof(uint32_t), stream, p, out, nzprev, mode);
     SF_HIP(hipGetLastError());
     return SF_OK;
   }
@@ -477,6 +497,10 @@ int sf_step_device(sf_env *env, const uint8_t *d_cmd, int32_t k) {
 int sf_observe(sf_env *env, float *out_host) {
   SF_ENV(env);
   return env->e.observe_host(out_host);
+}
+int sf_observe_device_delta(sf_env *env, float *d_out) {
+  SF_ENV(env);
+  return env->e.observe_device_delta(d_out);
 }
 int sf_observe_device(sf_env *env, float *d_out) {
   SF_ENV(env);

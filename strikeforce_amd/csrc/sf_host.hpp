@@ -160,6 +160,8 @@ struct Env {
   uint64_t *d_tb = nullptr, *d_serial = nullptr;
   uint8_t *d_cmd = nullptr;
   float *d_obs = nullptr;
+  uint32_t *d_nzprev = nullptr;      // [A * n_agents][961] which floats of the delta-tracked buffer are non-zero
+  const float *delta_ptr = nullptr;  // the buffer d_nzprev describes
   // host copies of the static map
   std::vector<uint8_t> map_flags;
   std::vector<int16_t> map_pidx;
@@ -300,7 +302,7 @@ struct Env {
 
   void destroy() {
     void *ptrs[] = {d_logt, d_exptab, d_tab, d_map_flags, d_map_pidx, d_map_exits, p.hum, p.zom, p.bul, p.por, p.rng, p.rng2, p.scal, p.results,
-                    p.flags, p.aux_dmg, p.aux_pidx, d_tb, d_serial, d_cmd, d_obs};
+                    p.flags, p.aux_dmg, p.aux_pidx, d_tb, d_serial, d_cmd, d_obs, d_nzprev};
     for (void *q : ptrs)
       if (q) rt.free(q);
     rt.shutdown();
@@ -332,7 +334,17 @@ struct Env {
   int observe_device(float *d_out) {
     if (!d_out) return fail(SF_ERR_ARG, "null observation buffer");
     if (!was_reset) return fail(SF_ERR_STATE, "sf_observe before sf_reset");
-    return rt.launch_observe(p, NB, d_out);
+    if (d_out == delta_ptr) delta_ptr = nullptr;  // a plain write: the non-zero map no longer describes this buffer
+    return rt.launch_observe(p, NB, d_out, nullptr, 0);
+  }
+  int observe_device_delta(float *d_out) {
+    if (!d_out) return fail(SF_ERR_ARG, "null observation buffer");
+    if (!was_reset) return fail(SF_ERR_STATE, "sf_observe before sf_reset");
+    int rc;
+    if (!d_nzprev && (rc = alloc(d_nzprev, (size_t)p.A * p.n_agents * 961))) return rc;
+    const int mode = d_out == delta_ptr ? 2 : 1;  // 1: write everything and record the map; 2: write the differences
+    delta_ptr = d_out;
+    return rt.launch_observe(p, NB, d_out, d_nzprev, mode);
   }
   int observe_host(float *out) {
     if (!out) return fail(SF_ERR_ARG, "null observation buffer");

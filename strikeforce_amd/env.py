@@ -44,6 +44,7 @@ def load_library():
         L.sf_destroy.restype = C.c_int
         L.sf_step_device.argtypes = [vp, vp, C.c_int32]
         L.sf_observe_device.argtypes = [vp, vp]
+        L.sf_observe_device_delta.argtypes = [vp, vp]
         L.sf_results_device.argtypes = [vp, vp]
         L.sf_done_device.argtypes = [vp, vp]
         L.sf_set_stream.argtypes = [vp, vp]
@@ -51,7 +52,7 @@ def load_library():
         L.sf_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.sf_config_defaults.argtypes = [C.POINTER(abi.Config)]
         L.sf_config_defaults.restype = None
-        for n in ("sf_step_device", "sf_observe_device", "sf_results_device", "sf_done_device", "sf_set_stream", "sf_synchronize",
+        for n in ("sf_step_device", "sf_observe_device", "sf_observe_device_delta", "sf_results_device", "sf_done_device", "sf_set_stream", "sf_synchronize",
                   "sf_kernel_time", "sf_abi_version"):
             getattr(L, n).restype = C.c_int
         L.sf_last_error.restype = C.c_char_p
@@ -61,7 +62,7 @@ def load_library():
 
 # every symbol include/strikeforce.h declares
 EXPORTS = ["sf_create", "sf_destroy", "sf_config_defaults", "sf_reset", "sf_step", "sf_step_device", "sf_observe",
-           "sf_observe_device", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
+           "sf_observe_device", "sf_observe_device_delta", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
            "sf_set_stream", "sf_synchronize", "sf_kernel_time", "sf_last_error", "sf_abi_version"]
 
 
@@ -123,6 +124,10 @@ class ArenaBatch:
                        dtype=np.float32)
         self._ck(self.L.sf_observe(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "sf_observe")
         return out
+
+    def observe_device_delta(self, d_out_ptr):
+        """observe_device for ONE persistent, caller-untouched buffer per env: only what changed is written."""
+        self._ck(self.L.sf_observe_device_delta(self.h, C.c_void_p(d_out_ptr)), "sf_observe_device_delta")
 
     def observe_device(self, d_out_ptr):
         self._ck(self.L.sf_observe_device(self.h, C.c_void_p(d_out_ptr)), "sf_observe_device")

@@ -123,7 +123,7 @@ struct CpuRT {
     }
     return SF_OK;
   }
-  int launch_observe(const Params &p, int, float *out) {
+  int launch_observe(const Params &p, int, float *out, uint32_t *, int) {  // (delta mode: same final buffer content)
     run_observe(p, out);
     return SF_OK;
   }

@@ -138,3 +138,33 @@ def test_errors_are_loud():
     g = env.ArenaBatch(w)
     with pytest.raises(env.StrikeForceError, match="before sf_reset"):
         g.step(np.full(1, ord("+"), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("name,arenas,steps", [("C2", 64, 60), ("C5", 4, 40), ("STRESS", 16, 80)])
+def test_delta_observation_equals_full_observation(name, arenas, steps):
+    """sf_observe_device_delta into one persistent buffer leaves, after every step, bit for bit what the plain call
+    writes into a scratch buffer — including agents that lose their observer (died) and arenas that restart."""
+    import torch
+    w = config.baseline_workload(name, arenas=arenas)
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    n = arenas * w.cfg.n_agents * 30752
+    keep = torch.full((n,), 7.0, dtype=torch.float32, device="cuda")   # garbage first: the first call must overwrite it
+    full = torch.empty(n, dtype=torch.float32, device="cuda")
+    cmds, _ = config.bench_commands(arenas, w.cfg.n_agents, steps)
+    d = _dev_cmds(cmds)
+    stride = arenas * w.cfg.n_agents
+    for s in range(steps):
+        g.observe_device_delta(keep.data_ptr())
+        g.observe_device(full.data_ptr())
+        g.synchronize()
+        assert torch.equal(keep.view(torch.int32), full.view(torch.int32)), "step %d" % s
+        g.step_device(d.data_ptr() + s * stride, 1)
+    # a plain write to the tracked buffer ends the tracking: the next delta call rewrites everything
+    keep.fill_(3.0)
+    g.observe_device(keep.data_ptr())
+    keep[5] = 9.0  # (the caller scribbles on it: allowed after a plain call)
+    g.observe_device_delta(keep.data_ptr())
+    g.observe_device(full.data_ptr())
+    g.synchronize()
+    assert torch.equal(keep.view(torch.int32), full.view(torch.int32))
