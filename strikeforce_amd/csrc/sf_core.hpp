@@ -48,7 +48,7 @@ struct Core {
     // _srand's 1024 serial draws (RN:73-74): log state, seed digits, draws done so far (0..1024)
     V rl2, rseed2;
     uint32_t warm;
-    uint32_t wrate;  // warm-up draws per call site (4 sites per step): 1 in long launches, 4 in short ones (step_body)
+    uint32_t wrate;  // warm-up draws per call site (4 sites per step)
     // RNG power table in LDS: 3^i (i < 256), then 3^(256 i)
     const uint32_t *xt;
     // one-deep lookahead of draw(): the log looked up for the next draw, and whether it is valid
@@ -1219,9 +1219,9 @@ struct Core {
     const P ag = W::ltu(W::lane(), (uint32_t)p.n_agents);
     // An episode shorter than its successor's warm-up stalls its own restart on the missing draws, and a launch is as
     // slow as its slowest arena: 17 % of configs[1]'s episodes are shorter than the 256 steps that 4 draws per step
-    // need, 0.7 % shorter than 64.  Long launches average such stalls away and keep the cheap rate; short (interactive)
-    // launches warm up four times faster.  Either way the adopted generator is the same.
-    S.wrate = k < 8 ? 4u : 1u;
+    // would need, 0.7 % shorter than the 64 steps of 16 per step.  Measured over 4 / 8 / 16 / 32 / 64 draws per step:
+    // 16 is the best for long launches (+1.7 % over 4) and for one-step launches (p90 128 -> 28 us).
+    S.wrate = 4u;
     for (int s = 0; s < k; ++s) {
       const uint8_t *c = cmds + ((size_t)s * (size_t)p.A + (size_t)a) * (size_t)p.n_agents;
       S.hcmd = W::select(ag, W::gload_u8(c, W::lane(), ag), V((uint32_t)'+'));
