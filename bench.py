@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-interactive", action="store_true", help="skip the K=1 + observation measurement")
     ap.add_argument("--no-policy", action="store_true", help="skip the closed loop with the on-device policy network")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] measurement")
     args = ap.parse_args()
 
     import torch
@@ -343,7 +344,7 @@ def main():
                              "frac": tf / MFMA_F32_PEAK_TFLOPS, "kernel": "k_gemm (%d launches per forward)" % pol["gemm_launches"],
                              "gemm_ms_per_forward": pol["gemm_ms"], "flop_per_agent_forward": pol["gemm_flop"] / pol["agents"]},
             }
-        if world == 1 and obs_n and args.workload == "C2":
+        if world == 1 and obs_n and args.workload == "C2" and not args.no_other_configs:
             out["other_configs"] = other_configs(args, local, torch, config, env)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)

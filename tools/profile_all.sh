@@ -4,7 +4,7 @@
 # tools/summarize_prof.py copies the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
-ARGS="--steps 1000 --warmup 100 --no-cpu-baseline"
+ARGS="--steps 1000 --warmup 100 --no-cpu-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -- python3 bench.py $ARGS > gpurun_out/prof/bench_stats.log 2>&1
 grep -h "sf::" gpurun_out/prof/stats/*/*_kernel_stats.csv
 PARGS="--steps 200 --warmup 400 --no-cpu-baseline --no-interactive"
