@@ -23,6 +23,10 @@
 
 namespace sf {
 
+#ifdef SF_DIAG_STAMPS
+__device__ uint32_t sf_diag_buffer[16 * 65536];  // diagnostic build only: [arena][phase] wave cycles of the last launch
+#endif
+
 // HP (HBM_PLANE): maps whose flag plane is too large for LDS keep it in HBM (sf_core.hpp); dynamic LDS = power table only
 template <int NB, bool HP>
 __global__ __launch_bounds__(64) void k_reset(Params p, const uint64_t *tb, const uint64_t *serial) {
@@ -541,6 +545,14 @@ int sf_synchronize(sf_env *env) {
   SF_ENV(env);
   return env->e.rt.sync();
 }
+#ifdef SF_DIAG_STAMPS
+int sf_diag_read(sf_env *env, uint32_t *out_host, int32_t arenas) {  // diagnostic build only (tools/diag_stamps.sh)
+  SF_ENV(env);
+  if (env->e.rt.sync() != SF_OK) return SF_ERR_DEVICE;
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(sf::sf_diag_buffer), (size_t)arenas * 16 * sizeof(uint32_t)) == hipSuccess
+             ? SF_OK : SF_ERR_DEVICE;
+}
+#endif
 int sf_kernel_time(sf_env *env, int32_t enable, float *ms, int32_t *launches) {
   SF_ENV(env);
   return env->e.rt.kernel_time(enable, ms, launches);

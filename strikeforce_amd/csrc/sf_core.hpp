@@ -61,6 +61,10 @@ struct Core {
     uint32_t jomle;
     uint32_t tb_lo, tb_hi, sr_lo, sr_hi;
     uint32_t dirty;  // the LDS flag plane differs from HBM
+#ifdef SF_DIAG_STAMPS
+    V dacc;  // diagnostic build only (tools/diag_stamps.sh): wave cycles per tick phase, lane = phase
+    uint32_t dlast;
+#endif
   };
 
   // ------------------------------------------------------------------------------------------------
@@ -444,6 +448,7 @@ struct Core {
         near |= W::ballot(zalive & ((qn0 == q) | (qn1 == q) | (qn2 == q) | (qn3 == q)));
       }
     }
+    SF_STAMP(S, 13);
     while (zm) {
       const uint32_t z = (uint32_t)W::ctz64(zm);
       const uint64_t bit = zm & (0ull - zm);
@@ -919,6 +924,7 @@ struct Core {
         W::setlane(S.hcmd, i, human_rnpc_bot(S, lds, p));
       }
     }
+    SF_STAMP(S, 9);
     const uint32_t r = draw(S, lds, p) & 1u;
     uint64_t m = alive;
     while (m) {
@@ -926,8 +932,11 @@ struct Core {
       m &= ~(1ull << i);
       // a human killed by obey() of an earlier one is impossible (hits land in hit_human), so `alive` is stable
       obey(S, lds, p, a, W::readlane(S.hcmd, i), i);
+      SF_STAMP(S, 10);
       teleport(S, lds, p, a, i);
+      SF_STAMP(S, 11);
       claim_chest(S, lds, p, i);
+      SF_STAMP(S, 12);
     }
     S.hcmd = V((uint32_t)'+');
   }
@@ -1044,19 +1053,28 @@ struct Core {
     S.ended = 0;
     if (S.done) return;
     // the two half-ticks share `update_tmp; hit_human; hit_zombie; ++frame; update_bull` (G:1457-1463,1465-1471)
+    SF_STAMP(S, 0);
     SF_NOUNROLL for (int half = 0; half < 2; ++half) {
       if (half == 0) {
         zombie_action(S, lds, p);
+        SF_STAMP(S, 1);
         portal_damage(S, lds, p);
+        SF_STAMP(S, 2);
       } else {
         human_action(S, lds, p, a);
+        SF_STAMP(S, 3);
       }
       if (p.auto_reset) prewarm(S, lds, p, S.wrate);  // warm-up draws of the next episode, spread over the step so that
+      SF_STAMP(S, 4);
       update_tmp(S, lds, p, a);             // each one's table lookup is in flight while the tick goes on
+      SF_STAMP(S, 5);
       hits(S, p);
+      SF_STAMP(S, 6);
       ++S.frame;  // updmap G:489-495 clears render-only bits
       if (p.auto_reset) prewarm(S, lds, p, S.wrate);
+      SF_STAMP(S, 4);
       update_bull(S, lds, p);
+      SF_STAMP(S, 7);
     }
     ++S.steps;
     // the loop top; when the episode ends and auto_reset is on, once more for the episode that begins
@@ -1073,6 +1091,7 @@ struct Core {
       S.episodes = ep;
       ++S.frame;  // G:1441
     }
+    SF_STAMP(S, 8);
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -1222,11 +1241,13 @@ struct Core {
     // would need, 0.7 % shorter than the 64 steps of 16 per step.  Measured over 4 / 8 / 16 / 32 / 64 draws per step:
     // 16 is the best for long launches (+1.7 % over 4) and for one-step launches (p90 128 -> 28 us).
     S.wrate = 4u;
+    SF_STAMP_BEGIN(S);
     for (int s = 0; s < k; ++s) {
       const uint8_t *c = cmds + ((size_t)s * (size_t)p.A + (size_t)a) * (size_t)p.n_agents;
       S.hcmd = W::select(ag, W::gload_u8(c, W::lane(), ag), V((uint32_t)'+'));
       step(S, lds, p, a);
     }
+    SF_STAMP_END(S, a);
     store(S, lds, p, a);
   }
 };

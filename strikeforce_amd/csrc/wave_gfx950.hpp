@@ -29,6 +29,28 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // 16 B per lane; a
 
 #define SF_PROF(ph)  // phase markers of the CPU emulator's op profile (tests/emu/wave_emu.hpp): nothing on the device
 
+// In-kernel phase stamps: compiled in only by the diagnostic build of tools/diag_stamps.sh (-DSF_DIAG_STAMPS), which
+// is never the product library.  Wave cycles (s_memtime) between consecutive stamps are charged to the phase named at
+// the later stamp, in lane `phase` of one register; the totals go to a buffer of their own (sf_diag_buffer).
+#ifdef SF_DIAG_STAMPS
+extern __device__ uint32_t sf_diag_buffer[];
+#define SF_STAMP_BEGIN(S) ((S).dacc = 0u, (S).dlast = (uint32_t)__builtin_amdgcn_s_memtime())
+#define SF_STAMP(S, ph)                                                              \
+  do {                                                                               \
+    const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime();                      \
+    (S).dacc = threadIdx.x == (ph) ? (S).dacc + (t_ - (S).dlast) : (S).dacc;         \
+    (S).dlast = t_;                                                                  \
+  } while (0)
+#define SF_STAMP_END(S, a) \
+  do {                     \
+    if (threadIdx.x < 16u) ::sf::sf_diag_buffer[(size_t)(a) * 16u + threadIdx.x] = (S).dacc; \
+  } while (0)
+#else
+#define SF_STAMP_BEGIN(S)
+#define SF_STAMP(S, ph)
+#define SF_STAMP_END(S, a)
+#endif
+
 struct WaveGfx950 {
   using V = uint32_t;
   using P = bool;

@@ -40,6 +40,9 @@ struct EmuProfScope {
   }
 };
 #define SF_PROF(ph) ::sf::EmuProfScope sf_prof_scope_(::sf::ph)
+#define SF_STAMP_BEGIN(S)  // in-kernel phase stamps exist only in the device's diagnostic build
+#define SF_STAMP(S, ph)
+#define SF_STAMP_END(S, a)
 #define EMU_OP() (++::sf::emu_prof().ops)
 #define EMU_SOP() (++::sf::emu_prof().sops)
 

@@ -15,7 +15,10 @@ def lib(asan=False):
     name = "libsf_emu_asan.so" if asan else "libsf_emu.so"
     if name not in _LIBS:
         d = os.path.join(ROOT, "tests", "emu")
-        subprocess.check_call(["make", "-s", "-C", d, name])
+        if not os.path.exists(os.path.join(d, name)) or os.path.isdir("/root/reference"):
+            # (re)built in the build container only (make is a no-op when up to date); elsewhere the file that
+            # __graft_entry__.build() made travels with the snapshot and nothing compiles under the tests
+            subprocess.check_call(["make", "-s", "-C", d, name])
         L = C.CDLL(os.path.join(d, name))
         L.sfe_create.argtypes = [C.POINTER(abi.Config)]
         L.sfe_create.restype = C.c_void_p

@@ -16,8 +16,10 @@ def lib():
     if _LIB is None:
         path = os.path.join(ROOT, "oracle", "libsf_oracle.so")
         src = os.path.join(ROOT, "oracle", "sf_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libsf_oracle.so"])
+        if not os.path.exists(path) or (os.path.getmtime(path) < os.path.getmtime(src) and os.path.isdir("/root/reference")):
+            # (re)built only in the build container, or when missing altogether: the GPU box uses the file that
+            # __graft_entry__.build() made, which travels with the snapshot
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libsf_oracle.so"])
         L = C.CDLL(path)
         L.sfo_create.argtypes = [C.POINTER(abi.Config)]
         L.sfo_create.restype = C.c_void_p
@@ -26,6 +28,15 @@ def lib():
         L.sfo_kat_rand.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_int32)]
         L.sfo_kat_compute_damage.argtypes = [C.c_int32, C.c_int32]
         L.sfo_kat_compute_damage.restype = C.c_int32
+        I32P = C.POINTER(C.c_int32)
+        L.sfo_kat_rand_state.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_int64)]
+        L.sfo_kat_rand_state.restype = None
+        L.sfo_kat_bullet.argtypes = [I32P, I32P] + [C.c_int32] * 5 + [I32P]
+        L.sfo_kat_bullet.restype = None
+        L.sfo_kat_character_hit.argtypes = [C.c_int32] * 4 + [I32P]
+        L.sfo_kat_character_hit.restype = None
+        L.sfo_kat_zombie.argtypes = [C.c_int32, I32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, I32P]
+        L.sfo_kat_zombie.restype = None
         L.sfo_draws.argtypes = [C.c_void_p, C.c_int32]
         L.sfo_draws.restype = C.c_int64
         L.sfo_bench_run.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]

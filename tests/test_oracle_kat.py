@@ -1,9 +1,13 @@
-"""The oracle against the known answers of the compiled reference."""
+"""The oracle against known answers of the reference itself: tests/golden/kat.json holds outputs of random.hpp:27-77,
+Item.hpp:27-194 and Character.hpp:29-47,225-287,832-871 compiled unmodified (oracle/ref_slices.py) and recorded by
+tests/golden/make_kat.py.  The fixture travels to machines without a checkout; tests/test_ref_slices.py compares the
+oracle with the compiled slices directly, over many more inputs, wherever oracle/_ref/libsf_refslice.so exists."""
 import ctypes as C
 import json
 import os
 
 import oracle_lib
+from strikeforce_amd import config
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
 
@@ -15,13 +19,46 @@ def test_rand_streams_match_reference():
         out = (C.c_int32 * n)()
         L.sfo_kat_rand(case["tb"], case["serial"], n, out)
         assert list(out) == case["first"], case
+        st = (C.c_int64 * 19)()
+        L.sfo_kat_rand_state(case["tb"], case["serial"], 4096, st)
+        assert list(st) == case["state_after_4096"], case
 
 
 def test_compute_damage_matches_reference():
     L = oracle_lib.lib()
-    for y, table in ((1, GOLD["compute_damage_y1"]), (100, GOLD["compute_damage_y100"])):
+    for y, table in GOLD["compute_damage"].items():
         for x, want in table.items():
-            assert L.sfo_kat_compute_damage(int(x), y) == want, (x, y)
+            assert L.sfo_kat_compute_damage(int(x), int(y)) == want, (x, y)
+
+
+def test_item_tables_match_reference():
+    """config.py's stat tables (what sf_config.items carries) are the values download_items() reads (IT:179-188)."""
+    it = GOLD["items"]
+    # reference rows: price vol lvl stamina | Hp effect  resp.  price vol lvl stamina | damage effect range
+    assert [tuple(r[3:6]) for r in it["cons"]] == config._CONS
+    assert [tuple(r[3:7]) for r in it["throw"]] == config._THROW
+    assert [tuple(r[3:7]) for r in it["weapon"]] == config._WEAPON
+
+
+def test_bullet_shot_and_expire_match_reference():
+    L = oracle_lib.lib()
+    for c in GOLD["bullet"]:
+        out = (C.c_int32 * 6)()
+        L.sfo_kat_bullet((C.c_int32 * 3)(*c["cor0"]), (C.c_int32 * 3)(*c["cor1"]), c["way"], c["damage"], c["effect"],
+                         c["range"], c["owner"], out)
+        assert list(out) == c["out"], c
+
+
+def test_character_hit_and_zombie_match_reference():
+    L = oracle_lib.lib()
+    for c in GOLD["character_hit"]:
+        out = (C.c_int32 * 2)()
+        L.sfo_kat_character_hit(c["hp"], c["mindamage"], c["damage"], c["effect"], out)
+        assert list(out) == c["out"], c
+    for c in GOLD["zombie"]:
+        out = (C.c_int32 * 11)()
+        L.sfo_kat_zombie(c["super"], (C.c_int32 * 3)(*c["cor"]), c["hits"], c["damage"], c["effect"], c["way"], out)
+        assert list(out) == c["out"], c
 
 
 def test_rand_is_ten_bits_and_deterministic():
