@@ -4,11 +4,17 @@
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
 A "step" is one pass of the hot path over one batch: every arena of every rank advances one iteration of
-the reference loop (gameplay.hpp:1443-1472).  Workload = BASELINE.json configs[1]: 4096 arenas per GPU,
-64x64 map, 1 player + 16 zombies, Solo, random-action agent; arenas are sharded across
-ranks with no data-path collective ("weak" scaling: 4096 arenas per GPU); the only collective is the RCCL
-all-gather of the end-of-episode result records after each launch.  Commands are resident in HBM before
-the timed region.  One JSON line is printed by rank 0.
+the reference loop (gameplay.hpp:1443-1472).  Workload = BASELINE.json configs[2], the configuration the metric is
+quoted on ("64x64 map x32 entities"): 4096 arenas per GPU, 64x64 map, 8 humans + 24 zombies (+ 64 bullet slots),
+Timer mode, random-action agent, NPC humans on human_rnpc_bot; arenas are sharded across ranks
+with no data-path collective ("weak" scaling: 4096 arenas per GPU); the only collective is the RCCL all-gather of
+the end-of-episode result records after each launch, issued through the library's C-ABI (sf_results_allgather) on
+a side stream.  Commands are resident in HBM before the timed region.  Before --warmup, an untimed pre-roll
+(PREROLL steps, full-length launches) brings zombie/NPC populations and clocks to steady state, so that the timed
+region is representative whatever --steps is.  One JSON line is printed by rank 0.
+
+With --gpus N > 1 and no torch.distributed environment, this process starts the N ranks itself (torch.distributed.run
+as a child process, before anything here touches a GPU) and passes their output through.
 """
 import argparse
 import ctypes as C
@@ -22,6 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PREROLL = 400  # untimed steps before --warmup (steady-state populations: a zombie every 20 steps, an NPC every 25)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: f32-input MFMA (v_mfma_f32_32x32x2_f32), dense
 
@@ -78,28 +85,63 @@ def cpu_baseline(workload_name, seconds=12.0):
                       % (arenas, workload_name, steps, dt, model, os.cpu_count() or 0)}
 
 
-def other_configs(args, local, torch, config, env):
-    """The same throughput measurement (commands resident, K steps per launch, one GPU) on BASELINE configs[2]: the
-    64x64 map with 32 entities (8 humans + 24 zombies, Timer mode, bullets and throwables active).  The headline is
-    quoted on configs[1]; this is the other reading of the metric's "64x64 map x32 entities"."""
-    w = config.baseline_workload("C3", arenas=args.arenas, device=local)
-    g = env.ArenaBatch(w)
-    g.set_stream(torch.cuda.current_stream().cuda_stream)
-    g.reset(*w.seeds())
-    steps, warm = 500, 100
-    cmds, _ = config.bench_commands(args.arenas, w.cfg.n_agents, steps + warm)
-    d = torch.from_numpy(cmds).cuda()
-    stride = args.arenas * w.cfg.n_agents
-    g.step_device(d.data_ptr(), warm)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(warm, warm + steps, args.k_per_launch):
-        g.step_device(d.data_ptr() + s * stride, min(args.k_per_launch, warm + steps - s))
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    g.close()
-    return {"configs[2] (C3): %d arenas, 64x64 map, 8 human + 24 zombie + 64 bullet slots, Timer" % args.arenas:
-            {"value": args.arenas * steps / dt, "unit": "env-steps/s", "steps": steps, "warmup": warm}}
+WORKLOAD_TEXT = {
+    "C2": "BASELINE configs[1] (C2)", "C3": "BASELINE configs[2] (C3)", "C4": "BASELINE configs[3] (C4)",
+    "C5": "BASELINE configs[4] (C5)"}
+
+
+def describe_workload(name, arenas, cfg):
+    mode = {0: "Solo", 1: "Timer", 2: "Squad", 3: "Battle"}.get(cfg.mode, str(cfg.mode))
+    return ("%s: %d arenas/GPU, %dx%d map, %d human + %d zombie + %d bullet slots, %s level %d, %d commanded "
+            "agent(s) per arena on the random-action agent" % (WORKLOAD_TEXT.get(name, name), arenas, cfg.rows, cfg.cols,
+                                                              cfg.cap_humans, cfg.cap_zombies, cfg.cap_bullets, mode,
+                                                              cfg.level, cfg.n_agents))
+
+
+def other_configs(args, local, torch, config, env, skip):
+    """The same throughput measurement (pre-roll, commands resident, K steps per launch, one GPU, 4096 arenas) on the
+    other BASELINE configurations that run on a GPU; parity for all of them is in tests/."""
+    out = {}
+    for name in ("C2", "C3", "C4", "C5"):
+        if name == skip:
+            continue
+        w = config.baseline_workload(name, arenas=args.arenas, device=local)
+        g = env.ArenaBatch(w)
+        g.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.reset(*w.seeds())
+        steps, pre = 300, PREROLL
+        cmds, _ = config.bench_commands(args.arenas, w.cfg.n_agents, steps + pre)
+        d = torch.from_numpy(cmds).cuda()
+        stride = args.arenas * w.cfg.n_agents
+        for s0 in range(0, pre, args.k_per_launch):
+            g.step_device(d.data_ptr() + s0 * stride, min(args.k_per_launch, pre - s0))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s0 in range(pre, pre + steps, args.k_per_launch):
+            g.step_device(d.data_ptr() + s0 * stride, min(args.k_per_launch, pre + steps - s0))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        g.close()
+        del d
+        out[describe_workload(name, args.arenas, w.cfg)] = {
+            "value": args.arenas * steps / dt, "unit": "env-steps/s", "steps": steps, "preroll": pre,
+            "algorithmic_bytes_per_arena_step": algorithmic_bytes_per_step(w.cfg)}
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks as a child process
+    (nothing in this process has touched a GPU) and pass its output and exit code through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env_ = dict(os.environ)
+    env_.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env_)
 
 
 def main():
@@ -107,14 +149,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--workload", default="C3")
     ap.add_argument("--arenas", type=int, default=4096, help="arenas per GPU")
     ap.add_argument("--k-per-launch", type=int, default=100, help="loop iterations per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-interactive", action="store_true", help="skip the K=1 + observation measurement")
     ap.add_argument("--no-policy", action="store_true", help="skip the closed loop with the on-device policy network")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] measurement")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other BASELINE configurations")
+    ap.add_argument("--preroll", type=int, default=PREROLL, help="untimed steady-state steps before --warmup")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -148,7 +194,8 @@ def main():
     tb, sr = shard.shard_seeds(w, rank)
     g.reset(tb, sr)
 
-    total = args.warmup + args.steps
+    pre = args.preroll
+    total = pre + args.warmup + args.steps
     cmds, _ = config.bench_commands(args.arenas, cfg.n_agents, total, seed0=shard.command_seed(w, rank))
     d_cmds = torch.from_numpy(cmds).cuda()  # resident in HBM before the timed region
     stride = args.arenas * cfg.n_agents
@@ -156,14 +203,15 @@ def main():
     # runs on RCCL's stream while launch i+1 computes: two buffer pairs, and a launch only waits for the gather that
     # used its pair two launches ago.  SF_BENCH_FORCE_GATHER=1 exercises this path with one rank.
     gather = world > 1 or os.environ.get("SF_BENCH_FORCE_GATHER") == "1"
-    if gather and world == 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     n_rec = args.arenas * cfg.n_agents * 8
-    res_local = [torch.zeros(n_rec, dtype=torch.int32, device="cuda") for _ in range(2)]
-    res_all = [torch.zeros(world * n_rec, dtype=torch.int32, device="cuda") for _ in range(2)] if gather else None
-    pending = [None, None]
+    rccl = gather and backend == "nccl"
+    if rccl:
+        # the communicator is the library's own (sf_comm_init); torch.distributed only carries rank 0's unique id
+        uid = [env.ArenaBatch.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        g.comm_init(uid[0], rank, world)
+        res_all = [torch.zeros(world * n_rec, dtype=torch.int32, device="cuda") for _ in range(2)]
     launches = [0]
 
     def run(first, count):
@@ -171,27 +219,22 @@ def main():
         while s < first + count:
             k = min(args.k_per_launch, first + count - s)
             g.step_device(d_cmds.data_ptr() + s * stride, k)
-            if gather:
-                j = launches[0] & 1
+            if rccl:  # sf_results_allgather: snapshot on the launch stream, ncclAllGather on the library's side stream
+                g.results_allgather(res_all[launches[0] & 1].data_ptr())
                 launches[0] += 1
-                if pending[j] is not None:
-                    pending[j].wait()  # stream-level: this pair's previous gather is done before it is overwritten
-                    pending[j] = None
-                g.results_device(res_local[j].data_ptr())
-                if backend == "nccl":
-                    pending[j] = dist.all_gather_into_tensor(res_all[j], res_local[j], async_op=True)
-                else:  # rehearsal backend: through host memory
-                    torch.cuda.current_stream().synchronize()
-                    shard.gather_results(res_local[j].cpu(), world)
+            elif gather:  # rehearsal backend (gloo, ranks sharing one card): through host memory
+                res = torch.zeros(n_rec, dtype=torch.int32, device="cuda")
+                g.results_device(res.data_ptr())
+                torch.cuda.current_stream().synchronize()
+                shard.gather_results(res.cpu(), world)
             s += k
 
     def drain():
-        for j in range(2):
-            if pending[j] is not None:
-                pending[j].wait()
-                pending[j] = None
+        if rccl:
+            g.comm_wait(host_too=True)
 
-    run(0, args.warmup)
+    run(0, pre)  # untimed pre-roll: full-length launches, populations and clocks at steady state
+    run(pre, args.warmup)
     drain()
     torch.cuda.synchronize()
     g.kernel_time(True)  # start timing step launches with HIP events on the launch stream
@@ -199,7 +242,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.warmup, args.steps)
+    run(pre + args.warmup, args.steps)
     drain()  # the gathers belong to the job: all of them are finished inside the timed region
     torch.cuda.synchronize()
     if world > 1:
@@ -294,6 +337,8 @@ def main():
         avg_launch_s = (k_ms / 1e3) / max(1, k_launches)
         steps_per_launch = args.steps / max(1, k_launches)
         achieved = bytes_step * args.arenas * steps_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        kpl_actual = int(round(steps_per_launch))
+        traffic = pmc_traffic(args.workload, args.arenas, kpl_actual) if abs(steps_per_launch - kpl_actual) < 1e-9 else None
         out = {
             "metric": "env-steps/sec (whole node), 64x64 map x32 entities",
             "value": env_steps / dt,
@@ -307,16 +352,23 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] (%s): %d arenas/GPU, %dx%d map, %d human + %d zombie + %d bullet"
-                                   " slots, Solo level %d, random-action agent"
-                                   % (args.workload, args.arenas, cfg.rows, cfg.cols, cfg.cap_humans, cfg.cap_zombies,
-                                      cfg.cap_bullets, cfg.level),
-                       "arenas_per_gpu": args.arenas, "steps_per_launch": args.k_per_launch,
-                       "parallelism": "arena-sharded x%d, no data-path collective" % world},
+            "config": {"workload": describe_workload(args.workload, args.arenas, cfg),
+                       "arenas_per_gpu": args.arenas, "steps_per_launch": steps_per_launch, "preroll_steps": pre,
+                       "parallelism": "arena-sharded x%d, no data-path collective; result records all-gathered over "
+                                      "RCCL (sf_results_allgather) after each launch" % world if world > 1 else
+                                      "one GPU, arena-sharded by construction (no data-path collective)"},
+            # contract figure: ALGORITHMIC bytes per launch / measured launch time against HBM peak.  `traffic` is the
+            # HBM bytes the counters saw for a launch of this length (None when that shape was not profiled): the arena
+            # state stays in registers/LDS across the K steps of a launch, so real HBM use is a few percent of the
+            # algorithmic figure and the kernel's actual limiter is instruction issue (scalar + vector), see `limiter`.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, args.arenas, args.k_per_launch),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_hbm_gbs": (traffic / avg_launch_s / 1e9) if (traffic and avg_launch_s > 0) else None,
                          "kernel": "k_step", "launches": k_launches, "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_bytes_per_arena_step": bytes_step},
+                         "steps_per_launch": steps_per_launch,
+                         "algorithmic_bytes_per_arena_step": bytes_step,
+                         "limiter": "instruction issue of the slot-ordered (scalar) game loops, not HBM: see "
+                                    "profiles/ (instruction mix, phase stamps) and DESIGN.md §6"},
         }
         obs_bytes = args.arenas * cfg.n_agents * (30752 * 4 + 961 * 8)
         if obs_n:
@@ -344,8 +396,8 @@ def main():
                              "frac": tf / MFMA_F32_PEAK_TFLOPS, "kernel": "k_gemm (%d launches per forward)" % pol["gemm_launches"],
                              "gemm_ms_per_forward": pol["gemm_ms"], "flop_per_agent_forward": pol["gemm_flop"] / pol["agents"]},
             }
-        if world == 1 and obs_n and args.workload == "C2" and not args.no_other_configs:
-            out["other_configs"] = other_configs(args, local, torch, config, env)
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs(args, local, torch, config, env, args.workload)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -191,6 +191,23 @@ int sf_observe_device_delta(sf_env *env, float *d_out);
 int sf_results(sf_env *env, int32_t *out_host);
 int sf_results_device(sf_env *env, int32_t *d_out);
 
+/* ---- multi-GPU: the one exchange step ------------------------------------------
+ * Arenas are sharded over one sf_env per GPU with no data-path collective.  The result records of all shards are
+ * exchanged with an RCCL all-gather over xGMI.  The reference has no counterpart (its only inter-process traffic is the
+ * TCP command relay, gameplay.hpp:113-118,170-193); what this replaces is every client simulating every arena.
+ * RCCL is loaded on first use; the communicator is the library's own.  Bootstrap: rank 0 calls sf_comm_unique_id and
+ * hands the SF_COMM_ID_BYTES bytes to the other ranks by any means (torch.distributed, MPI, a file); every rank then
+ * calls sf_comm_init on its env. */
+#define SF_COMM_ID_BYTES 128
+int sf_comm_unique_id(uint8_t *id);
+int sf_comm_init(sf_env *env, const uint8_t *id, int32_t rank, int32_t world);
+/* Snapshot this env's result records on its stream and all-gather the snapshots of all ranks into d_out
+ * ([world][arenas][n_agents][8] int32, device memory) on a side stream owned by the library: the call returns at
+ * once and the gather runs beside the launches that follow.  d_out is complete after sf_comm_wait. */
+int sf_results_allgather(sf_env *env, int32_t *d_out);
+/* Make the env's stream (and, with host_too != 0, the calling thread) wait for every gather issued so far. */
+int sf_comm_wait(sf_env *env, int32_t host_too);
+
 /* Replaces the loop exit test `if(check_end()) break;` gameplay.hpp:1450. */
 int sf_done(sf_env *env, uint8_t *out_host);
 /* The same flag on the device, one byte per (arena, agent) (every agent of an arena gets its arena's flag), in the

@@ -8,6 +8,8 @@
 // There is no CPU path: without a HIP device every entry point fails with SF_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstddef>
 
 #include <new>
@@ -449,11 +451,67 @@ struct HipRT {
   }
 };
 
+// The one exchange step of the multi-GPU path: an RCCL all-gather of the end-of-episode result
+// records, issued on a stream of the library's own so that it runs beside the next launch.  RCCL is loaded on first
+// use (dlopen; single-GPU users never map it) and the communicator is the library's own: the caller only carries
+// the 128-byte unique id from rank 0 to the other ranks (torch.distributed, MPI, a file: anything).
+struct ncclUniqueIdBytes {  // ncclUniqueId of rccl.h: 128 opaque bytes, passed by value
+  char internal[SF_COMM_ID_BYTES];
+};
+struct Comm {
+  typedef int (*get_id_t)(void *);
+  typedef int (*init_rank_t)(void **, int, ncclUniqueIdBytes, int);
+  typedef int (*all_gather_t)(const void *, void *, size_t, int, void *, hipStream_t);
+  typedef int (*destroy_t)(void *);
+  typedef const char *(*err_t)(int);
+  void *dl = nullptr;
+  get_id_t get_id = nullptr;
+  init_rank_t init_rank = nullptr;
+  all_gather_t all_gather = nullptr;
+  destroy_t destroy_fn = nullptr;
+  err_t err = nullptr;
+  void *comm = nullptr;
+  int world = 0, rank = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+  int32_t *staging[2] = {nullptr, nullptr};
+  bool used[2] = {false, false};
+  unsigned issued = 0;
+
+  int load() {
+    if (dl) return SF_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names)
+      if ((dl = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!dl) return fail(SF_ERR_DEVICE, std::string("RCCL not found: ") + dlerror());
+    get_id = (get_id_t)dlsym(dl, "ncclGetUniqueId");
+    init_rank = (init_rank_t)dlsym(dl, "ncclCommInitRank");
+    all_gather = (all_gather_t)dlsym(dl, "ncclAllGather");
+    destroy_fn = (destroy_t)dlsym(dl, "ncclCommDestroy");
+    err = (err_t)dlsym(dl, "ncclGetErrorString");
+    if (!get_id || !init_rank || !all_gather || !destroy_fn || !err) return fail(SF_ERR_DEVICE, "RCCL lacks a symbol");
+    return SF_OK;
+  }
+  int nccl(int rc, const char *what) { return rc == 0 ? SF_OK : fail(SF_ERR_DEVICE, std::string(what) + ": " + err(rc)); }
+  void shutdown() {
+    if (comm) (void)destroy_fn(comm), comm = nullptr;
+    for (int j = 0; j < 2; ++j) {
+      if (ready[j]) (void)hipEventDestroy(ready[j]), ready[j] = nullptr;
+      if (done[j]) (void)hipEventDestroy(done[j]), done[j] = nullptr;
+      if (staging[j]) (void)hipFree(staging[j]), staging[j] = nullptr;
+    }
+    if (side) (void)hipStreamDestroy(side), side = nullptr;
+  }
+};
+
 }  // namespace sf
 
 struct sf_env {
   sf::Env<sf::HipRT> e;
+  sf::Comm comm;
 };
+
+using sf::fail;  // SF_HIP in the entry points below
 
 extern "C" {
 
@@ -479,6 +537,7 @@ int sf_create(const sf_config *cfg, sf_env **out) {
 }
 int sf_destroy(sf_env *env) {
   if (!env) return SF_OK;
+  env->comm.shutdown();
   env->e.destroy();
   delete env;
   return SF_OK;
@@ -544,6 +603,64 @@ int sf_set_stream(sf_env *env, void *hip_stream) {
 int sf_synchronize(sf_env *env) {
   SF_ENV(env);
   return env->e.rt.sync();
+}
+int sf_comm_unique_id(uint8_t *id) {
+  if (!id) return sf::fail(SF_ERR_ARG, "null id buffer");
+  sf::Comm c;
+  int rc = c.load();
+  if (rc) return rc;
+  return c.nccl(c.get_id(id), "ncclGetUniqueId");  // (the handle of a loaded library is reference-counted by dlopen)
+}
+int sf_comm_init(sf_env *env, const uint8_t *id, int32_t rank, int32_t world) {
+  SF_ENV(env);
+  sf::Comm &c = env->comm;
+  if (!id || world < 1 || rank < 0 || rank >= world) return sf::fail(SF_ERR_ARG, "bad communicator arguments");
+  if (c.comm) return sf::fail(SF_ERR_ARG, "communicator already initialised");
+  int rc = c.load();
+  if (rc) return rc;
+  SF_HIP(hipSetDevice(env->e.rt.device));
+  sf::ncclUniqueIdBytes uid;
+  memcpy(uid.internal, id, sizeof uid.internal);
+  rc = c.nccl(c.init_rank(&c.comm, world, uid, rank), "ncclCommInitRank");
+  if (rc) return rc;
+  c.world = world, c.rank = rank;
+  SF_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+  const size_t bytes = (size_t)env->e.p.A * env->e.p.n_agents * 8 * sizeof(int32_t);
+  for (int j = 0; j < 2; ++j) {
+    SF_HIP(hipEventCreateWithFlags(&c.ready[j], hipEventDisableTiming));
+    SF_HIP(hipEventCreateWithFlags(&c.done[j], hipEventDisableTiming));
+    SF_HIP(hipMalloc((void **)&c.staging[j], bytes));
+  }
+  return SF_OK;
+}
+int sf_results_allgather(sf_env *env, int32_t *d_out) {
+  SF_ENV(env);
+  sf::Comm &c = env->comm;
+  if (!c.comm) return sf::fail(SF_ERR_ARG, "sf_comm_init has not been called");
+  if (!d_out) return sf::fail(SF_ERR_ARG, "null gather buffer");
+  hipStream_t st = env->e.rt.stream;
+  const size_t count = (size_t)env->e.p.A * env->e.p.n_agents * 8;
+  const int j = (int)(c.issued++ & 1u);
+  // the records are snapshotted on the simulation stream (later launches latch new ones), the gather of the snapshot
+  // runs on the side stream; a snapshot buffer is reused only after the gather that read it has finished
+  if (c.used[j]) SF_HIP(hipStreamWaitEvent(st, c.done[j], 0));
+  SF_HIP(hipMemcpyAsync(c.staging[j], env->e.p.results, count * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  SF_HIP(hipEventRecord(c.ready[j], st));
+  SF_HIP(hipStreamWaitEvent(c.side, c.ready[j], 0));
+  int rc = c.nccl(c.all_gather(c.staging[j], d_out, count, 2 /* ncclInt32 */, c.comm, c.side), "ncclAllGather");
+  if (rc) return rc;
+  SF_HIP(hipEventRecord(c.done[j], c.side));
+  c.used[j] = true;
+  return SF_OK;
+}
+int sf_comm_wait(sf_env *env, int32_t host_too) {
+  SF_ENV(env);
+  sf::Comm &c = env->comm;
+  if (!c.comm) return sf::fail(SF_ERR_ARG, "sf_comm_init has not been called");
+  for (int j = 0; j < 2; ++j)
+    if (c.used[j]) SF_HIP(hipStreamWaitEvent(env->e.rt.stream, c.done[j], 0));
+  if (host_too) SF_HIP(hipStreamSynchronize(c.side));
+  return SF_OK;
 }
 #ifdef SF_DIAG_STAMPS
 int sf_diag_read(sf_env *env, uint32_t *out_host, int32_t arenas) {  // diagnostic build only (tools/diag_stamps.sh)

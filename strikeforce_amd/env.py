@@ -50,6 +50,12 @@ def load_library():
         L.sf_set_stream.argtypes = [vp, vp]
         L.sf_synchronize.argtypes = [vp]
         L.sf_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.sf_comm_unique_id.argtypes = [C.c_char_p]
+        L.sf_comm_init.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
+        L.sf_results_allgather.argtypes = [vp, vp]
+        L.sf_comm_wait.argtypes = [vp, C.c_int32]
+        for n in ("sf_comm_unique_id", "sf_comm_init", "sf_results_allgather", "sf_comm_wait"):
+            getattr(L, n).restype = C.c_int
         L.sf_config_defaults.argtypes = [C.POINTER(abi.Config)]
         L.sf_config_defaults.restype = None
         for n in ("sf_step_device", "sf_observe_device", "sf_observe_device_delta", "sf_results_device", "sf_done_device", "sf_set_stream", "sf_synchronize",
@@ -63,7 +69,8 @@ def load_library():
 # every symbol include/strikeforce.h declares
 EXPORTS = ["sf_create", "sf_destroy", "sf_config_defaults", "sf_reset", "sf_step", "sf_step_device", "sf_observe",
            "sf_observe_device", "sf_observe_device_delta", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
-           "sf_set_stream", "sf_synchronize", "sf_kernel_time", "sf_last_error", "sf_abi_version"]
+           "sf_set_stream", "sf_synchronize", "sf_kernel_time", "sf_last_error", "sf_abi_version",
+           "sf_comm_unique_id", "sf_comm_init", "sf_results_allgather", "sf_comm_wait"]
 
 
 class ArenaBatch:
@@ -139,6 +146,26 @@ class ArenaBatch:
 
     def results_device(self, d_out_ptr):
         self._ck(self.L.sf_results_device(self.h, C.c_void_p(d_out_ptr)), "sf_results_device")
+
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from rank 0 (ncclGetUniqueId through the library's own RCCL): hand them to every rank."""
+        L = load_library()
+        buf = C.create_string_buffer(128)
+        rc = L.sf_comm_unique_id(buf)
+        if rc != 0:
+            raise StrikeForceError("sf_comm_unique_id failed (%d): %s" % (rc, L.sf_last_error().decode()))
+        return buf.raw
+
+    def comm_init(self, uid, rank, world):
+        self._ck(self.L.sf_comm_init(self.h, uid, rank, world), "sf_comm_init")
+
+    def results_allgather(self, d_out_ptr):
+        """RCCL all-gather of every rank's result records into [world][arenas][agents][8] int32, on a side stream."""
+        self._ck(self.L.sf_results_allgather(self.h, C.c_void_p(d_out_ptr)), "sf_results_allgather")
+
+    def comm_wait(self, host_too=False):
+        self._ck(self.L.sf_comm_wait(self.h, 1 if host_too else 0), "sf_comm_wait")
 
     def done_device(self, d_out_ptr):
         """check_end()'s verdict on the device, one byte per (arena, agent): what PolicyBatch.reset_memory takes."""

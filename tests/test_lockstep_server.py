@@ -89,7 +89,7 @@ def run_match(make_sim, teams, quit_at=None, ticks=400):
     threads = [threading.Thread(target=client_thread, args=(k,)) for k in range(n)]
     for t in threads:
         t.start()
-        time.sleep(0.05)  # connection order = player index
+        time.sleep(0.3)  # connection order = player index (the server hands out indices in accept order)
     for t in threads:
         t.join(timeout=120)
     try:
