@@ -51,6 +51,8 @@ struct Core {
     uint32_t wrate;  // warm-up draws per call site (4 sites per step)
     // RNG power table in LDS: 3^i (i < 256), then 3^(256 i)
     const uint32_t *xt;
+    // human_action's command-class / stat table in LDS (Tables::hatab, sf_types.hpp HT_*)
+    const uint32_t *ht;
     // one-deep lookahead of draw(): the log looked up for the next draw, and whether it is valid
     V la;  // valid whenever draw() can run: (re)issued by load(), srand_(), the adoption of a warmed-up generator, draw()
     // the same for the next episode's generator (prewarm_one)
@@ -910,6 +912,46 @@ struct Core {
   }
 
   // human_action G:965-1012.  S.hcmd holds this step's external commands on lanes < n_agents.
+  //
+  // The reference sweeps the live humans in slot order (ascending or descending by one draw): obey; teleport;
+  // claim_chest for each.  What one human does can matter to a later one only through a cell both touch (a move's
+  // target or origin, a placed block or portal, a fresh bullet) or through the bullet / portal slot pools.  So the
+  // sweep is first evaluated for all humans at once, one lane each, against the state at the start of the sweep, and
+  // the cells every human reads or writes are compared: if no two humans meet on a cell, nobody stands on or steps
+  // onto a portal entrance, and the bullet pool cannot run dry, the lane-parallel result IS the sweep's (moves,
+  // selections, consumables, stamina and ammunition are applied per lane; the bullets are allocated by a short
+  // slot-ordered loop, because `b_ind` hands out slots in sweep order; the rare block / portal placements run through
+  // obey() itself, in sweep order).  Otherwise the sweep runs one human at a time (human_action_serial: obey /
+  // teleport / claim_chest as the reference has them), from the same untouched state.
+  static SF_DEV void human_action_serial(Arena &S, uint8_t *lds, const Params &p, int a, uint64_t alive, uint32_t r) {
+    uint64_t m = alive;
+    while (m) {
+      const uint32_t i = r ? (uint32_t)W::ctz64(m) : (uint32_t)(63 - W::clz64(m));
+      m &= ~(1ull << i);
+      // a human killed by obey() of an earlier one is impossible (hits land in hit_human), so `alive` is stable
+      obey(S, lds, p, a, W::readlane(S.hcmd, i), i);
+      SF_STAMP(S, 10);
+      teleport(S, lds, p, a, i);
+      SF_STAMP(S, 11);
+      claim_chest(S, lds, p, i);
+      SF_STAMP(S, 12);
+    }
+  }
+  static SF_DEV V get16v(const V &lo, const V &hi, const V &k) {  // k in 0..3, per lane
+    return W::shrv(W::select(W::ltu(k, 2u), lo, hi), (k & 1u) << 4) & 0xffffu;
+  }
+  static SF_DEV void set16v(V &lo, V &hi, const V &k, const V &val, P pred) {
+    const V sh = (k & 1u) << 4;
+    const V keep = ~W::shlv(V(0xffffu), sh);
+    const V ins = W::shlv(val & 0xffffu, sh);
+    const P low = W::ltu(k, 2u);
+    lo = W::select(pred & low, (lo & keep) | ins, lo);
+    hi = W::select(pred & (!low), (hi & keep) | ins, hi);
+  }
+  static SF_DEV V set_vec_sel_v(const V &fl, uint32_t vec_plus1, const V &sel) {  // sel per lane, 0-based
+    return (fl & ~((3u << HF_VEC_SH) | (15u << HF_IND_SH))) | (vec_plus1 << HF_VEC_SH) | ((sel + 1u) << HF_IND_SH);
+  }
+
   static SF_DEV void human_action(Arena &S, uint8_t *lds, const Params &p, int a) {
     SF_PROF(PH_HUMAN);
     const uint64_t alive = W::ballot((S.hfl & HF_ALIVE) != 0u) & capmask(p.H);
@@ -926,17 +968,187 @@ struct Core {
     }
     SF_STAMP(S, 9);
     const uint32_t r = draw(S, lds, p) & 1u;
-    uint64_t m = alive;
+    if (!alive) {
+      S.hcmd = V((uint32_t)'+');
+      return;
+    }
+    // ---- one lane per human: what would it do, and to which cell --------------------------------------------
+    const P live = W::frombits(alive);
+    const V cw = W::lds_u32(S.ht, (S.hcmd >> 2) & 31u, live & W::ltu(S.hcmd, 128u));
+    const V c8 = W::shrv(cw, (S.hcmd & 3u) << 3) & 255u;
+    const V cls = c8 & 15u, prm = c8 >> 4;
+    const V q0 = S.hpos;
+    const V hr = (q0 >> 10) & 1023u, hc = q0 & 1023u, hf = (q0 >> 20) & 3u;
+    const V way = S.hfl & HF_WAY_MASK;
+    const P is_move = live & (cls == (uint32_t)CL_MOVE);
+    const P is_place = live & ((cls == (uint32_t)CL_BLOCK) | (cls == (uint32_t)CL_PORTAL));
+    const P is_shoot = live & ((cls == (uint32_t)CL_PUNCH) | (cls == (uint32_t)CL_FIRE));
+    const V dir = W::select(is_move, prm, way - 1u);
+    const V rr = hr + W::select(dir == 0u, V(1u), W::select(dir == 2u, V(0xffffffffu), V(0u)));
+    const V cc = hc + W::select(dir == 1u, V(1u), W::select(dir == 3u, V(0xffffffffu), V(0u)));
+    const P inb = (is_move | is_place | is_shoot) & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
+    const V tq = (q0 & (3u << 20)) | (rr << 10) | cc;
+    const V oci = (hf * (uint32_t)p.N + hr) * (uint32_t)p.M + hc;
+    const V tci = (hf * (uint32_t)p.N + rr) * (uint32_t)p.M + cc;
+    const V tfl = W::lds_u8(lds, tci, inb);
+    const V ofl = W::lds_u8(lds, oci, live);
+    // who is on the target cells; do two humans meet on a cell
+    const uint64_t movers = W::ballot(is_move);
+    const uint64_t placers = W::ballot(is_place & inb);
+    const uint64_t needb = W::ballot(inb & (((tfl & SF_CELL_POUT) != 0u) | is_place));
+    uint64_t occH = 0ull, occZ = 0ull, occB = 0ull;
+    bool slow = W::ballot(live & ((ofl & (SF_CELL_PIN_UP | SF_CELL_PIN_DN | SF_CELL_CHEST)) != 0u)) != 0ull;
+    {
+      uint64_t m = W::ballot(inb);
+      while (m) {
+        const uint32_t i = (uint32_t)W::ctz64(m);
+        const uint64_t bit = m & (0ull - m);
+        m ^= bit;
+        const uint32_t q = W::readlane(tq, i);
+        const uint64_t hs = W::ballot(((S.hfl & HF_OCC) != 0u) & (S.hpos == q));
+        const uint64_t same = W::ballot(inb & (tq == q));
+        if (hs) occH |= bit;
+        if (W::ballot((S.zpos & (ZF_ALIVE | POS_MASK)) == (ZF_ALIVE | q))) occZ |= bit;
+        if ((needb & bit) && refbullet_at(S, q) >= 0) occB |= bit;
+        // the human standing there may move away in this sweep; another human aims at the same cell
+        if ((hs & movers) || (same & (same - 1ull))) slow = true;
+      }
+    }
+    const P oH = W::frombits(occH), oZ = W::frombits(occZ), oB = W::frombits(occB);
+    const P t_wall = (tfl & SF_CELL_WALL) != 0u, t_pin = (tfl & (SF_CELL_PIN_UP | SF_CELL_PIN_DN)) != 0u;
+    // showit() of the target is one of '?', '^', 'v', '.', '*' (G:750-756): not a wall, nobody on it, and not a bare 'O'
+    const P bare_out = ((tfl & SF_CELL_POUT) != 0u) & (!t_pin) & ((tfl & SF_CELL_CHEST) == 0u) & (!oB);
+    const P pass = is_move & inb & (!t_wall) & (!oH) & (!oZ) & (!bare_out);
+    if (W::ballot(pass & t_pin)) slow = true;  // steps onto a portal entrance: teleport() follows
+    const uint64_t shooters = W::ballot(is_shoot & inb);
+    if (shooters) {  // `index = b_ind(); if(index == -1) return;` must not trigger for anybody
+      int freeb = 0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int left = p.B - 64 * j;
+        if (left > 0) freeb += W::popc64(~W::ballot((S.ba[j] & BA_ALIVE) != 0u) & capmask(left));
+      }
+      if (freeb < W::popc64(shooters)) slow = true;
+    }
+    SF_COUNT(slow ? 1 : 0);  // (test build: how often the sweep falls back to one human at a time)
+    if (slow) {
+      human_action_serial(S, lds, p, a, alive, r);
+      S.hcmd = V((uint32_t)'+');
+      return;
+    }
+    // ---- the sweep, all humans at once -------------------------------------------------------------------------
+    const V prof_base = W::select((S.hfl & HF_PROF) != 0u, V((uint32_t)(HT_PROF + HT_PROF_STRIDE)), V((uint32_t)HT_PROF));
+    const V vec1 = (S.hfl >> HF_VEC_SH) & 3u;          // backpack.vec + 1
+    const V sel = ((S.hfl >> HF_IND_SH) & 15u) - 1u;   // backpack.ind (0xffffffff: none)
+    V nfl = S.hfl;
+    // '_'  G:696-699
+    S.hhp = W::select(live & (cls == (uint32_t)CL_SUICIDE), V(0u), S.hhp);
+    // turn_l / turn_r CH:745-759
+    {
+      const V nw = W::select(prm != 0u, W::select(way == 1u, V(4u), way - 1u), W::select(way == 4u, V(1u), way + 1u));
+      nfl = W::select(live & (cls == (uint32_t)CL_TURN), (nfl & ~HF_WAY_MASK) | nw, nfl);
+    }
+    // selections G:759-791: a consumable / throwable needs stock, a weapon its level
+    {
+      const P sc = live & (cls == (uint32_t)CL_SELC) & (get16v(S.hc01, S.hc23, prm) != 0u);
+      const P st = live & (cls == (uint32_t)CL_SELT) & (get16v(S.ht01, S.ht23, prm) != 0u);
+      const P is_w = live & (cls == (uint32_t)CL_SELW);
+      const P sw = is_w & (W::lds_u32(S.ht, prof_base + (uint32_t)HT_P_WLVL + prm, is_w) != 0u);
+      nfl = W::select(sc, set_vec_sel_v(nfl, 1u, prm), nfl);
+      nfl = W::select(st, set_vec_sel_v(nfl, 2u, prm), nfl);
+      nfl = W::select(sw, set_vec_sel_v(nfl, 3u, prm), nfl);
+    }
+    // 'u': Human::use CH:379-389
+    {
+      const V k = sel & 3u;
+      const V n = get16v(S.hc01, S.hc23, k);
+      const P use = live & (cls == (uint32_t)CL_USE) & (vec1 == 1u) & (n != 0u);
+      if (W::ballot(use)) {
+        const V ci = k * 3u + (uint32_t)HT_CONS;
+        S.hst = S.hst + W::lds_u32(S.ht, ci, use);
+        S.hhp = S.hhp + W::lds_u32(S.ht, ci + 1u, use);
+        S.hmd = S.hmd + W::lds_u32(S.ht, ci + 2u, use);
+        set16v(S.hc01, S.hc23, k, n - 1u, use);
+        nfl = W::select(use & (n == 1u), nfl & ~(3u << HF_VEC_SH), nfl);  // vec = -1, ind kept
+      }
+    }
+    // moves G:742-758, then claim_chest G:507-515 on the cell reached
+    if (W::ballot(pass)) {
+      S.hpos = W::select(pass, tq, S.hpos);
+      const P got = pass & ((tfl & SF_CELL_CHEST) != 0u);
+      const uint64_t gm = W::ballot(got);
+      if (gm) {
+        const V ci = ((tfl >> SF_CELL_CONS_SHIFT) & 3u) * 3u + (uint32_t)HT_CONS;  // Human::claim_chest CH:372-377
+        S.hst = S.hst + W::lds_u32(S.ht, ci, got);
+        S.hhp = S.hhp + W::lds_u32(S.ht, ci + 1u, got);
+        S.hmd = S.hmd + W::lds_u32(S.ht, ci + 2u, got);
+        W::lds_store_u8(lds, tci, tfl & ~(uint32_t)(SF_CELL_CHEST | (3u << SF_CELL_CONS_SHIFT)), got);
+        S.dirty = 1u;
+        S.chests -= W::popc64(gm);
+      }
+    }
+    // punch / throw / shoot G:796-819: stamina and ammunition are spent whenever a slot is free and the target is on
+    // the map, even if the bullet then cannot enter the cell
+    V bdmg = V(0u), beff = V(0u), brange = V(1u);
+    uint64_t fire = 0ull;
+    if (shooters) {
+      const P sh = is_shoot & inb;
+      const P punch = sh & (cls == (uint32_t)CL_PUNCH);
+      const P thr = sh & (cls == (uint32_t)CL_FIRE) & (vec1 == 2u);
+      const P gun = sh & (cls == (uint32_t)CL_FIRE) & (vec1 == 3u);
+      const V md = S.hmd;
+      // Human::punch CH:391-397
+      const V cdp = W::lds_u32(S.ht, prof_base + (uint32_t)HT_P_CDPUNCH, punch);
+      bdmg = W::select(punch, W::select(W::gts(cdp, md), cdp, md), bdmg);
+      P can = punch;
+      // Human::throw_it CH:410-427
+      if (W::ballot(thr)) {
+        const V k = sel & 3u;
+        const V tb_ = prof_base + (uint32_t)HT_P_THR + (k << 2);
+        const V t0 = W::lds_u32(S.ht, tb_, thr), t1 = W::lds_u32(S.ht, tb_ + 1u, thr);
+        const V t2 = W::lds_u32(S.ht, tb_ + 2u, thr), t3 = W::lds_u32(S.ht, tb_ + 3u, thr);
+        const V n = get16v(S.ht01, S.ht23, k);
+        const P tired = W::gts(V(0u), S.hst + t0);  // stamina + cost < 0
+        const P empty = thr & (!tired) & (n == 0u);
+        const P ok = thr & (!tired) & (n != 0u);
+        nfl = W::select(empty | (ok & (n == 1u)), nfl & ~(3u << HF_VEC_SH), nfl);
+        S.hst = W::select(ok, S.hst + t0, S.hst);
+        set16v(S.ht01, S.ht23, k, n - 1u, ok);
+        bdmg = W::select(thr, W::select(W::gts(t1, t1 + md), t1, t1 + md), bdmg);
+        beff = W::select(thr, t2, beff), brange = W::select(thr, t3, brange);
+        can = can | ok;
+      }
+      // Human::shot_it CH:399-408
+      if (W::ballot(gun)) {
+        const V k = sel & 7u;
+        const V wb = prof_base + (uint32_t)HT_P_WEAPON + (k << 2);
+        const V w0 = W::lds_u32(S.ht, wb, gun), w1 = W::lds_u32(S.ht, wb + 1u, gun);
+        const V w2 = W::lds_u32(S.ht, wb + 2u, gun), w3 = W::lds_u32(S.ht, wb + 3u, gun);
+        const V cdw = W::lds_u32(S.ht, prof_base + (uint32_t)HT_P_CDW + k, gun);
+        const P ok = gun & (!W::gts(V(0u), S.hst + w0));
+        S.hst = W::select(ok, S.hst + w0, S.hst);
+        bdmg = W::select(gun, W::select(W::gts(cdw, w1 + md), cdw, w1 + md), bdmg);
+        beff = W::select(gun, w2, beff), brange = W::select(gun, w3, brange);
+        can = can | ok;
+      }
+      // `(sit != '#' && sit != 'v' && sit != '^') || s[10]`  G:812: a character on an entrance hides it (showit order)
+      const P enter = ((tfl & SF_CELL_TEMP) != 0u) | ((!t_wall) & ((!t_pin) | oH | oZ));
+      fire = W::ballot(can & enter);
+    }
+    S.hfl = nfl;
+    // the order-dependent rest, in sweep order: slot allocation of the bullets; block / portal placement through obey()
+    uint64_t m = fire | placers;
     while (m) {
       const uint32_t i = r ? (uint32_t)W::ctz64(m) : (uint32_t)(63 - W::clz64(m));
-      m &= ~(1ull << i);
-      // a human killed by obey() of an earlier one is impossible (hits land in hit_human), so `alive` is stable
-      obey(S, lds, p, a, W::readlane(S.hcmd, i), i);
-      SF_STAMP(S, 10);
-      teleport(S, lds, p, a, i);
-      SF_STAMP(S, 11);
-      claim_chest(S, lds, p, i);
-      SF_STAMP(S, 12);
+      const uint64_t bit = 1ull << i;
+      m &= ~bit;
+      if (placers & bit) {
+        obey(S, lds, p, a, W::readlane(S.hcmd, i), i);
+      } else {
+        const int index = b_ind(S, p);  // never -1 here (checked above)
+        bullet_put(S, index, W::readlane(tq, i), (int)W::readlane(way, i), (int)W::readlane(bdmg, i),
+                   (int)(int32_t)W::readlane(beff, i), (int)W::readlane(brange, i), (int)i + 1);
+      }
     }
     S.hcmd = V((uint32_t)'+');
   }
@@ -1212,8 +1424,10 @@ struct Core {
   // plane) is the arena's slice of Params::flags
   static SF_DEV uint8_t *tables(Arena &S, uint8_t *lds, const Params &p, int a) {
     uint8_t *tab = lds;
-    W::copy_g2l(tab, reinterpret_cast<const uint8_t *>(p.exptab), 2048u);
+    W::copy_g2l(tab, reinterpret_cast<const uint8_t *>(p.exptab), (uint32_t)LDS_EXP_BYTES);
+    W::copy_g2l(tab + LDS_EXP_BYTES, reinterpret_cast<const uint8_t *>(p.tab->hatab), (uint32_t)(HT_WORDS * 4));
     S.xt = reinterpret_cast<const uint32_t *>(tab);
+    S.ht = reinterpret_cast<const uint32_t *>(tab + LDS_EXP_BYTES);
     S.la = V(0u);
     S.la2 = V(0u), S.la2_ok = 0u;
     return HBM_PLANE ? p.flags + (size_t)a * (size_t)p.cells_pad : lds + LDS_TABLE_BYTES;

@@ -84,6 +84,33 @@ inline void finish_derived(Derived &d) {
   for (int i = 0; i < 8; ++i) d.cd_weapon[i] = host_compute_damage(d.weapon[i][1], d.weapon[i][3]);
 }
 
+// Tables::hatab (sf_types.hpp HT_*): obey()'s key classes (gameplay.hpp:695-821) and the per-profile stats its
+// shooting / selection branches read, as one flat table that the step kernel keeps in LDS
+inline void fill_hatab(Tables &t) {
+  memset(t.hatab, 0, sizeof t.hatab);
+  uint8_t *cmd = reinterpret_cast<uint8_t *>(t.hatab + HT_CMD);
+  auto put = [&](char c, int cls, int prm) { cmd[(unsigned char)c] = (uint8_t)(cls | (prm << 4)); };
+  put('_', CL_SUICIDE, 0), put('[', CL_BLOCK, 0), put(']', CL_PORTAL, 0), put('q', CL_TURN, 0), put('e', CL_TURN, 1);
+  put('s', CL_MOVE, 0), put('d', CL_MOVE, 1), put('w', CL_MOVE, 2), put('a', CL_MOVE, 3);
+  const char *selc = "fghj", *selt = "kl;'", *selw = "cvbnm,./";
+  for (int k = 0; k < 4; ++k) put(selc[k], CL_SELC, k), put(selt[k], CL_SELT, k);
+  for (int k = 0; k < 8; ++k) put(selw[k], CL_SELW, k);
+  put('u', CL_USE, 0), put('z', CL_PUNCH, 0), put('x', CL_FIRE, 0);
+  for (int pr = 0; pr < 2; ++pr) {
+    uint32_t *w = t.hatab + HT_PROF + pr * HT_PROF_STRIDE;
+    const Derived &d = t.der[pr];
+    w[HT_P_CDPUNCH] = (uint32_t)d.cd_punch;
+    for (int k = 0; k < 8; ++k) {
+      w[HT_P_WLVL + k] = (uint32_t)d.weapon_lvl[k], w[HT_P_CDW + k] = (uint32_t)d.cd_weapon[k];
+      for (int j = 0; j < 4; ++j) w[HT_P_WEAPON + 4 * k + j] = (uint32_t)d.weapon[k][j];
+    }
+    for (int k = 0; k < 4; ++k)
+      for (int j = 0; j < 4; ++j) w[HT_P_THR + 4 * k + j] = (uint32_t)d.thr[k][j];
+  }
+  for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 3; ++j) t.hatab[HT_CONS + 3 * k + j] = (uint32_t)t.cons_items[k][j];
+}
+
 inline int validate(const sf_config *c) {
   if (!c) return fail(SF_ERR_ARG, "null config");
   if (c->abi_version != SF_ABI_VERSION) return fail(SF_ERR_ARG, "abi_version mismatch");
@@ -205,6 +232,7 @@ struct Env {
     finish_derived(tab.der[0]), finish_derived(tab.der[1]);
     for (int i = 0; i < 4; ++i)
       for (int k = 0; k < 3; ++k) tab.cons_items[i][k] = cfg.items.cons[i][k];
+    fill_hatab(tab);
     for (int i = 0; i < SF_MAX_AGENTS; ++i) {
       if (cfg.agent_team[i] < 0 || cfg.agent_team[i] > 255) return fail(SF_ERR_ARG, "agent_team must be 0..255");
       tab.teams[i] = cfg.agent_team[i];

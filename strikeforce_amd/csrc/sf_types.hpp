@@ -72,6 +72,14 @@ struct Derived {
   int32_t cd_weapon[8];      // compute_damage(w.damage, w.range)     Character.hpp:404
 };
 
+// ---- human_action's decode / stat table, staged in LDS (sf_core.hpp human_action) ------------------------------
+// words: [HT_CMD .. +32)   128 bytes: command char -> class | param << 4 (obey's key classes, gameplay.hpp:695-821)
+//        [HT_PROF + 72 prof .. ): cd_punch, weapon_lvl[8], cd_weapon[8], weapon[8][4], thr[4][4]   (Derived)
+//        [HT_CONS .. +12)  cons_items[4][3]
+enum { HT_CMD = 0, HT_PROF = 32, HT_PROF_STRIDE = 72, HT_P_CDPUNCH = 0, HT_P_WLVL = 1, HT_P_CDW = 9, HT_P_WEAPON = 17,
+       HT_P_THR = 49, HT_CONS = HT_PROF + 2 * HT_PROF_STRIDE, HT_WORDS = 256 };
+enum { CL_NOP = 0, CL_SUICIDE, CL_BLOCK, CL_PORTAL, CL_TURN, CL_MOVE, CL_SELC, CL_SELT, CL_SELW, CL_USE, CL_PUNCH, CL_FIRE };
+
 struct Tables {
   Derived der[2];
   int32_t cons_items[4][3];  // stamina, Hp, effect
@@ -82,6 +90,7 @@ struct Tables {
   // nothing on them) and which of their features are non-zero: the same for every arena and every call
   float class_rec[8][32];
   uint32_t class_mask[8];
+  uint32_t hatab[HT_WORDS];  // see HT_* above; copied to LDS by every step launch
 };
 
 // ---- everything a kernel needs -----------------------------------------------------------------------
@@ -117,7 +126,8 @@ constexpr int LOGT_OFF = 512;
 constexpr int LOGT_ENTRIES = LOGT_OFF + 65537;
 
 inline int nb_for(int B) { return (B + 63) / 64; }
-constexpr int LDS_TABLE_BYTES = 2048;  // exptab
+constexpr int LDS_EXP_BYTES = 2048;                                   // exptab
+constexpr int LDS_TABLE_BYTES = LDS_EXP_BYTES + HT_WORDS * 4;         // exptab, then Tables::hatab
 inline size_t lds_bytes_for(int cells_pad) { return (size_t)cells_pad + LDS_TABLE_BYTES; }
 // flag planes above this size stay in HBM (Core<.., HBM_PLANE>): staging them would leave < 12 wavefronts per CU
 constexpr int LDS_PLANE_MAX = 12 * 1024;

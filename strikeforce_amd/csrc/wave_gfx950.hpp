@@ -27,6 +27,7 @@ static __device__ __forceinline__ SF_GLOBAL T *gptr(T *p) {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // 16 B per lane; a builtin vector, usable in any address space
 
+#define SF_COUNT(k)  // event counters of the CPU emulator (tests/emu/wave_emu.hpp): nothing on the device
 #define SF_PROF(ph)  // phase markers of the CPU emulator's op profile (tests/emu/wave_emu.hpp): nothing on the device
 
 // In-kernel phase stamps: compiled in only by the diagnostic build of tools/diag_stamps.sh (-DSF_DIAG_STAMPS), which
@@ -84,6 +85,15 @@ struct WaveGfx950 {
     return (uint32_t)x;
   }
   static SF_DEV V minu(V a, V b) { return a < b ? a : b; }
+  static SF_DEV V shrv(V a, V sh) { return a >> sh; }  // per-lane shift amounts (< 32)
+  static SF_DEV V shlv(V a, V sh) { return a << sh; }
+  static SF_DEV P gts(V a, V b) { return (int32_t)a > (int32_t)b; }  // signed
+  static SF_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
+  // per-lane byte store into the LDS flag plane (distinct cells per lane)
+  static SF_DEV void lds_store_u8(uint8_t *lds, V idx, V val, P pred) {
+    if (pred) lds[idx] = (uint8_t)val;
+    __builtin_amdgcn_wave_barrier();
+  }
   // low 32 bits of a product whose operands are below 2^24 (v_mul_u32_u24)
   static SF_DEV V mul24(V a, V b) {
     uint32_t r;

@@ -148,6 +148,11 @@ int sfe_profile(uint64_t *out) {
   q.ops = q.mark = 0, q.sops = q.smark = 0;
   return sf::PH_COUNT;
 }
+// SF_COUNT(k) path counters of the device source; clears them (out: 8 words)
+void sfe_counts(uint64_t *out) {
+  sf::EmuProf &q = sf::emu_prof();
+  for (int i = 0; i < 8; ++i) out[i] = q.counts[i], q.counts[i] = 0;
+}
 sfe_env *sfe_create(const sf_config *cfg) {
   sfe_env *env = new sfe_env();
   if (env->e.create(cfg) != SF_OK) {

@@ -19,6 +19,7 @@ struct EmuProf {
   uint64_t ops = 0, mark = 0, by[PH_COUNT] = {};
   uint64_t sops = 0, smark = 0, sby[PH_COUNT] = {};  // wave-uniform accesses (readlane, ballot, setlane, uniform LDS)
   int phase = PH_OTHER;
+  uint64_t counts[8] = {};  // SF_COUNT(k): how often the device source took path k (tests assert both kinds occur)
 };
 inline EmuProf &emu_prof() {
   static EmuProf p;
@@ -40,6 +41,7 @@ struct EmuProfScope {
   }
 };
 #define SF_PROF(ph) ::sf::EmuProfScope sf_prof_scope_(::sf::ph)
+#define SF_COUNT(k) (++::sf::emu_prof().counts[(k) & 7])
 #define SF_STAMP_BEGIN(S)  // in-kernel phase stamps exist only in the device's diagnostic build
 #define SF_STAMP(S, ph)
 #define SF_STAMP_END(S, a)
@@ -180,6 +182,30 @@ struct WaveEmu {
     V r;
     for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i];
     return r;
+  }
+  static V shrv(const V &a, const V &sh) {
+    EMU_OP();
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] >> (sh.v[i] & 31u);
+    return r;
+  }
+  static V shlv(const V &a, const V &sh) {
+    EMU_OP();
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] << (sh.v[i] & 31u);
+    return r;
+  }
+  static P gts(const V &a, const V &b) {
+    EMU_OP();
+    P r{0};
+    for (int i = 0; i < 64; ++i) r.m |= (uint64_t)((int32_t)a.v[i] > (int32_t)b.v[i]) << i;
+    return r;
+  }
+  static int popc64(uint64_t m) { return __builtin_popcountll(m); }
+  static void lds_store_u8(uint8_t *lds, const V &idx, const V &val, P pred) {
+    EMU_OP();
+    for (int i = 0; i < 64; ++i)
+      if ((pred.m >> i) & 1ull) lds[idx.v[i]] = (uint8_t)val.v[i];
   }
   static V mul24(const V &a, const V &b) {  // operands below 2^24, like v_mul_u32_u24
     EMU_OP();

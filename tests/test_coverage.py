@@ -34,3 +34,17 @@ def test_stress_runs_every_pool_dry():
     ev = _run("STRESS", 6, 900)
     assert ev["no_bullet_slot"] > 0 and ev["zombie_spawn"] > 0 and ev["npc_spawn"] > 0
     assert ev["episode_end"] > 0  # 600-frame Timer clock: episodes end and restart inside the run
+
+
+def test_human_action_takes_both_of_its_forms():
+    """human_action evaluates the sweep lane-parallel when no two humans meet on a cell and falls back to one human at a
+    time otherwise (sf_core.hpp): both forms must occur in the parity runs, or one of them is untested."""
+    import ctypes as C
+    import emu_lib
+    L = emu_lib.lib()
+    cn = (C.c_uint64 * 8)()
+    L.sfe_counts(cn)  # clear
+    for name, arenas, steps in (("C3", 4, 500), ("STRESS", 6, 600), ("MAXCAP", 2, 120)):
+        _run(name, arenas, steps)
+        L.sfe_counts(cn)
+        assert cn[0] > 100 and cn[1] > 5, (name, cn[0], cn[1])
