@@ -53,6 +53,8 @@ struct Core {
     const uint32_t *xt;
     // human_action's command-class / stat table in LDS (Tables::hatab, sf_types.hpp HT_*)
     const uint32_t *ht;
+    // BM_COUNT scratch bitmaps in LDS, one bit per cell, all-zero between uses ("cell bitmaps" below); null with HBM_PLANE
+    uint32_t *bm;
     // one-deep lookahead of draw(): the log looked up for the next draw, and whether it is valid
     V la;  // valid whenever draw() can run: (re)issued by load(), srand_(), the adoption of a warmed-up generator, draw()
     // the same for the next episode's generator (prewarm_one)
@@ -415,42 +417,61 @@ struct Core {
     const V zr = (zq >> 10) & 1023u, zc = zq & 1023u;
     // neighbour d of each zombie: packed position and "clear flag byte" bit
     V freebits = V(0u);
+    V hnear = V(0u);  // bit d: a human (cell designation s[0]) stands on neighbour d
     const V ci0 = ((zq >> 20) * (uint32_t)p.N + zr) * (uint32_t)p.M + zc;  // the zombie's own cell index
-    for (int d = 0; d < 4; ++d) {
-      const V rr = zr + (uint32_t)DX(d), cc = zc + (uint32_t)DY(d);
-      const P inb = zalive & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
-      const V ci = ci0 + (uint32_t)(DX(d) * p.M + DY(d));
-      const V fl = W::lds_u8(lds, ci, inb);
-      freebits = freebits | W::select(inb & (fl == 0u), V(1u << d), V(0u));
-    }
     const V qn0 = zq + 1024u, qn1 = zq + 1u, qn2 = zq - 1024u, qn3 = zq - 1u;  // DX/DY order: down, right, up, left
-    // designated bullets present at phase start: own cell -> skip; neighbour cell -> not '.'
     uint64_t skip = 0ull;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      uint64_t bm = W::ballot((S.ba[j] & BA_REF) != 0u);
-      while (bm) {
-        const uint32_t l = (uint32_t)W::ctz64(bm);
-        bm &= bm - 1ull;
-        const uint32_t q = W::readlane(S.ba[j], l) & POS_MASK;
-        skip |= W::ballot(zalive & (zq == q));
-        const V hit = W::select(qn0 == q, V(1u), V(0u)) | W::select(qn1 == q, V(2u), V(0u)) |
-                      W::select(qn2 == q, V(4u), V(0u)) | W::select(qn3 == q, V(8u), V(0u));
-        freebits = freebits & ~hit;
+    if (!HBM_PLANE) {
+      // humans and designated bullets scatter their cells into bitmaps; every zombie tests its own cell (a bullet
+      // there: skip) and its four neighbours (a bullet: not '.'; a human: punch)
+      const P hocc = (S.hfl & HF_OCC) != 0u;
+      const V hci = cell_index_v(p, S.hpos);
+      bm_set(S, p, BM_HUM, hci, hocc);
+      bm_bullets(S, p, BM_REF, true);
+      skip = W::ballot(zalive & bm_test(S, p, BM_REF, ci0, zalive));
+      for (int d = 0; d < 4; ++d) {
+        const V rr = zr + (uint32_t)DX(d), cc = zc + (uint32_t)DY(d);
+        const P inb = zalive & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
+        const V ci = ci0 + (uint32_t)(DX(d) * p.M + DY(d));
+        const V fl = W::lds_u8(lds, ci, inb);
+        const P clear = inb & (fl == 0u) & (!bm_test(S, p, BM_REF, ci, inb));
+        freebits = freebits | W::select(clear, V(1u << d), V(0u));
+        hnear = hnear | W::select(inb & bm_test(S, p, BM_HUM, ci, inb), V(1u << d), V(0u));
       }
-    }
-    // humans (cell designation s[0]) next to a zombie
-    uint64_t near = 0ull;
-    {
+      bm_clear(S, p, BM_HUM, hci, hocc);
+      bm_bullets(S, p, BM_REF, false);
+    } else {
+      for (int d = 0; d < 4; ++d) {
+        const V rr = zr + (uint32_t)DX(d), cc = zc + (uint32_t)DY(d);
+        const P inb = zalive & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
+        const V ci = ci0 + (uint32_t)(DX(d) * p.M + DY(d));
+        const V fl = W::lds_u8(lds, ci, inb);
+        freebits = freebits | W::select(inb & (fl == 0u), V(1u << d), V(0u));
+      }
+      // designated bullets present at phase start: own cell -> skip; neighbour cell -> not '.'
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        uint64_t bm = W::ballot((S.ba[j] & BA_REF) != 0u);
+        while (bm) {
+          const uint32_t l = (uint32_t)W::ctz64(bm);
+          bm &= bm - 1ull;
+          const uint32_t q = W::readlane(S.ba[j], l) & POS_MASK;
+          skip |= W::ballot(zalive & (zq == q));
+          const V hit = W::select(qn0 == q, V(1u), V(0u)) | W::select(qn1 == q, V(2u), V(0u)) |
+                        W::select(qn2 == q, V(4u), V(0u)) | W::select(qn3 == q, V(8u), V(0u));
+          freebits = freebits & ~hit;
+        }
+      }
+      // humans next to a zombie (the packed compare can alias across a row end: the loop below re-checks exactly)
       uint64_t hm = W::ballot((S.hfl & HF_OCC) != 0u);
       while (hm) {
         const uint32_t h = (uint32_t)W::ctz64(hm);
         hm &= hm - 1ull;
         const uint32_t q = W::readlane(S.hpos, h);
-        near |= W::ballot(zalive & ((qn0 == q) | (qn1 == q) | (qn2 == q) | (qn3 == q)));
+        hnear = hnear | W::select(zalive & ((qn0 == q) | (qn1 == q) | (qn2 == q) | (qn3 == q)), V(15u), V(0u));
       }
     }
-    SF_STAMP(S, 13);
+    const uint64_t near = W::ballot(hnear != 0u);
     while (zm) {
       const uint32_t z = (uint32_t)W::ctz64(zm);
       const uint64_t bit = zm & (0ull - zm);
@@ -461,12 +482,14 @@ struct Core {
         const uint32_t q0 = W::readlane(zq, z);
         const int f = pos_f(q0), r = pos_r(q0), c = pos_c(q0);
         const int zmd = (int)W::readlane(S.zmd, z);
+        const uint32_t hn = W::readlane(hnear, z);
         bool b = false;
         for (int i1 = 0; i1 < 4; ++i1) {
+          if (!((hn >> i1) & 1u)) continue;
           const int rr = r + DX(i1), cc = c + DY(i1);
           if (!inmap(p, rr, cc)) continue;
           const uint32_t q = pos_pack(f, rr, cc);
-          if (human_at(S, q) >= 0) {
+          if (!HBM_PLANE || human_at(S, q) >= 0) {
             int index = b_ind(S, p);
             if (refbullet_at(S, q) < 0 && index != -1)  // Zombie::punch CH:838-844
               bullet_put(S, index, q, i1 + 1, zmd > 0 ? zmd : 0, 0, 1, 0);
@@ -495,6 +518,37 @@ struct Core {
   static SF_DEV void portal_damage(Arena &S, uint8_t *lds, const Params &p) {
     SF_PROF(PH_PORTAL);
     uint64_t pm = W::ballot((S.ppos & PF_ACTIVE) != 0u) & capmask(p.P);
+    if (!HBM_PLANE) {
+      if (!pm) return;
+      // an exit radiates unless it shows 'O': 'O' flag, no wall / entrance / chest flag, nobody and no designated
+      // bullet on it (showit order G:321-346).  All exits at once: flags by gather, occupancy by cell bitmaps
+      const P act = ((S.ppos & PF_ACTIVE) != 0u) & W::ltu(W::lane(), (uint32_t)p.P);
+      const V pci = cell_index_v(p, S.ppos);
+      const V fl = W::lds_u8(lds, pci, act);
+      const P plain = act & ((fl & (uint32_t)(SF_CELL_WALL | SF_CELL_PIN_UP | SF_CELL_PIN_DN | SF_CELL_CHEST | SF_CELL_POUT)) ==
+                             (uint32_t)SF_CELL_POUT);
+      uint64_t need = pm;
+      if (W::ballot(plain)) {
+        const P hocc = (S.hfl & HF_OCC) != 0u, zlive = (S.zpos & ZF_ALIVE) != 0u;
+        const V hci = cell_index_v(p, S.hpos), zci = cell_index_v(p, S.zpos);
+        bm_set(S, p, BM_HUM, hci, hocc);
+        bm_set(S, p, BM_ZOM, zci, zlive);
+        bm_bullets(S, p, BM_REF, true);
+        const P covered = bm_test(S, p, BM_HUM, pci, plain) | bm_test(S, p, BM_ZOM, pci, plain) | bm_test(S, p, BM_REF, pci, plain);
+        bm_clear(S, p, BM_HUM, hci, hocc);
+        bm_clear(S, p, BM_ZOM, zci, zlive);
+        bm_bullets(S, p, BM_REF, false);
+        need = pm & ~W::ballot(plain & (!covered));
+      }
+      while (need) {
+        const uint32_t i = (uint32_t)W::ctz64(need);
+        need &= need - 1ull;
+        int index = b_ind(S, p);
+        if (index == -1) return;
+        bullet_put(S, index, W::readlane(S.ppos, i) & POS_MASK, 3, 20, -10, 1, 0);  // radiation.ready(20, -10, 1); shot(v, 3, radiation, 0)
+      }
+      return;
+    }
     while (pm) {
       const uint32_t i = (uint32_t)W::ctz64(pm);
       pm &= pm - 1ull;
@@ -588,10 +642,101 @@ struct Core {
   }
 
   // ------------------------------------------------------------------------------------------------
+  // Cell bitmaps.  "Is somebody on cell q" for ONE cell is a lane compare + ballot; for many cells at once (every
+  // bullet against every character, every zombie's neighbourhood against humans and bullets) that would be a loop of
+  // ballots.  With the flag plane in LDS there is room for scratch bitmaps of one bit per cell next to it: one kind of
+  // entity scatters its cells into a bitmap (LDS atomic OR, one instruction for all lanes), the other kind tests its
+  // own cells (one gather), the bits are cleared again.  The bitmaps are all-zero outside such a build / test / clear
+  // bracket.  Big maps (HBM_PLANE) keep the ballot loops.
+  enum { BM_HUM = 0, BM_ZOM = 1, BM_REF = 2, BM_TMP = 3 };
+  static SF_DEV V cell_index_v(const Params &p, const V &q) {  // packed position (flag bits above it ignored) -> cell
+    return W::mad24(W::mad24((q >> 20) & 3u, (uint32_t)p.N, (q >> 10) & 1023u), (uint32_t)p.M, q & 1023u);
+  }
+  static SF_DEV void bm_set(Arena &S, const Params &p, int which, const V &ci, P pred) {
+    W::lds_or_u32(S.bm + which * p.bm_words, ci >> 5, W::shlv(V(1u), ci & 31u), pred);
+  }
+  static SF_DEV void bm_clear(Arena &S, const Params &p, int which, const V &ci, P pred) {
+    W::lds_store_u32(S.bm + which * p.bm_words, ci >> 5, V(0u), pred);
+  }
+  static SF_DEV P bm_test(const Arena &S, const Params &p, int which, const V &ci, P pred) {
+    return (W::shrv(W::lds_u32(S.bm + which * p.bm_words, ci >> 5, pred), ci & 31u) & 1u) != 0u;
+  }
+  // set bit, telling whether it was set already (by an earlier build or by another lane of this very call)
+  static SF_DEV P bm_claim(Arena &S, const Params &p, int which, const V &ci, P pred) {
+    const V bit = W::shlv(V(1u), ci & 31u);
+    return pred & ((W::lds_or_rtn_u32(S.bm + which * p.bm_words, ci >> 5, bit, pred) & bit) != 0u);
+  }
+  static SF_DEV void bm_bullets(Arena &S, const Params &p, int which, bool set) {  // the designated bullets' cells
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const P ref = (S.ba[j] & BA_REF) != 0u;
+      const V ci = cell_index_v(p, S.ba[j]);
+      if (set)
+        bm_set(S, p, which, ci, ref);
+      else
+        bm_clear(S, p, which, ci, ref);
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
   // hit_human + hit_zombie G:574-652.  A cell holds at most one character and a hit consumes only the
   // cell's designated bullet, so the two slot-ordered sweeps reduce to: (1) humans already at Hp <= 0 die
   // (lane-parallel); (2) one wave-uniform pass over designated bullets that share a cell with a live
   // character.  All cross-entity effects are additive (owner damage/effect/kills, loot, kill counters).
+  // one hit: the designated bullet in slot `slot` on human hv (>= 0) or zombie zv
+  static SF_DEV void hit_one(Arena &S, const Params &p, uint32_t my_team, int slot, int hv, int zv) {
+    const uint32_t l = (uint32_t)slot & 63u;
+    uint32_t dmgu = 0u, bb = 0u;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (j == (slot >> 6)) {
+        dmgu = W::readlane(S.bd[j], l), bb = W::readlane(S.bb[j], l);
+        W::setlane(S.ba[j], l, 0u);  // pix->s[2] = 0; mb[...] = false
+      }
+    const int32_t dmg = (int32_t)dmgu;
+    const int32_t eff = (int32_t)(int16_t)(bb & 0xffffu);
+    const int owner = (int)(bb >> 16);  // human slot + 1, 0 = none
+    const uint32_t ofl = owner ? W::readlane(S.hfl, (uint32_t)(owner - 1)) : 0u;
+    const uint32_t owner_team = (uint32_t)h_team(ofl);
+    if (hv >= 0) {  // human_damage G:611-634
+      const uint32_t vfl = W::readlane(S.hfl, (uint32_t)hv);
+      const uint32_t vteam = (uint32_t)h_team(vfl);
+      const int32_t hp = (int32_t)W::readlane(S.hhp, (uint32_t)hv) - dmg;  // Character::hit CH:242-246
+      W::setlane(S.hhp, (uint32_t)hv, (uint32_t)hp);
+      add_lane(S.hmd, (uint32_t)hv, eff);
+      const bool cross = owner && vteam != owner_team;
+      if (cross) {
+        add_lane(S.hdm, (uint32_t)(owner - 1), dmg);
+        add_lane(S.hef, (uint32_t)(owner - 1), eff);
+      }
+      if (hp <= 0) {
+        W::setlane(S.hfl, (uint32_t)hv, hv == p.ind ? (vfl & ~HF_ALIVE) : (vfl & ~(HF_ALIVE | HF_CTRL | HF_OCC)));
+        if (owner && owner_team == my_team && vteam != my_team) {
+          ++S.tkills, S.loot += 100;
+          if (owner == p.ind + 1) S.loot += 900, ++S.kills;
+        }
+        if (cross) add_lane(S.hk, (uint32_t)(owner - 1), 1);
+      }
+    } else {  // zombie_damage G:574-598
+      const uint32_t zp = W::readlane(S.zpos, (uint32_t)zv);
+      const int32_t hp = (int32_t)W::readlane(S.zhp, (uint32_t)zv) - dmg;
+      W::setlane(S.zhp, (uint32_t)zv, (uint32_t)hp);
+      add_lane(S.zmd, (uint32_t)zv, eff);
+      if (owner) {
+        add_lane(S.hdm, (uint32_t)(owner - 1), dmg);
+        add_lane(S.hef, (uint32_t)(owner - 1), eff);
+      }
+      if (hp <= 0) {
+        W::setlane(S.zpos, (uint32_t)zv, 0u);
+        if (owner && owner_team == my_team) {
+          const int pts = 500 + ((zp & ZF_SUPER) ? 250 : 0);
+          ++S.tkills, S.loot += pts / 10;
+          if (owner == p.ind + 1) S.loot += pts * 9 / 10, ++S.kills;
+        }
+        if (owner) add_lane(S.hk, (uint32_t)(owner - 1), 1);
+      }
+    }
+  }
   static SF_DEV void hits(Arena &S, const Params &p) {
     SF_PROF(PH_HITS);
     {
@@ -600,6 +745,30 @@ struct Core {
       S.hfl = W::select(dying, W::select(W::lane() == (uint32_t)p.ind, S.hfl & ~HF_ALIVE, S.hfl & ~(HF_ALIVE | HF_CTRL | HF_OCC)), S.hfl);
     }
     const uint32_t my_team = (uint32_t)h_team(W::readlane(S.hfl, (uint32_t)p.ind));
+    if (!HBM_PLANE) {
+      // who stands on a designated bullet: the bullets scatter their cells, the characters test their own
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) any = any || W::ballot((S.ba[j] & BA_REF) != 0u) != 0ull;
+      if (!any) return;
+      bm_bullets(S, p, BM_REF, true);
+      const P hlive = (S.hfl & HF_ALIVE) != 0u;
+      const P zlive = (S.zpos & ZF_ALIVE) != 0u;
+      uint64_t hm = W::ballot(bm_test(S, p, BM_REF, cell_index_v(p, S.hpos), hlive) & hlive);
+      uint64_t zmk = W::ballot(bm_test(S, p, BM_REF, cell_index_v(p, S.zpos), zlive) & zlive);
+      bm_bullets(S, p, BM_REF, false);
+      while (hm) {
+        const uint32_t i = (uint32_t)W::ctz64(hm);
+        hm &= hm - 1ull;
+        hit_one(S, p, my_team, refbullet_at(S, W::readlane(S.hpos, i)), (int)i, -1);
+      }
+      while (zmk) {
+        const uint32_t i = (uint32_t)W::ctz64(zmk);
+        zmk &= zmk - 1ull;
+        hit_one(S, p, my_team, refbullet_at(S, W::readlane(S.zpos, i) & POS_MASK), -1, (int)i);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       uint64_t m = W::ballot((S.ba[j] & BA_REF) != 0u);
@@ -610,51 +779,7 @@ struct Core {
         const int hv = live_human_at(S, q);
         const int zv = hv >= 0 ? -1 : zombie_at(S, q);
         if (hv < 0 && zv < 0) continue;
-        const int32_t dmg = (int32_t)W::readlane(S.bd[j], l);
-        const uint32_t bb = W::readlane(S.bb[j], l);
-        const int32_t eff = (int32_t)(int16_t)(bb & 0xffffu);
-        const int owner = (int)(bb >> 16);  // human slot + 1, 0 = none
-        W::setlane(S.ba[j], l, 0u);        // pix->s[2] = 0; mb[...] = false
-        const uint32_t ofl = owner ? W::readlane(S.hfl, (uint32_t)(owner - 1)) : 0u;
-        const uint32_t owner_team = (uint32_t)h_team(ofl);
-        if (hv >= 0) {  // human_damage G:611-634
-          const uint32_t vfl = W::readlane(S.hfl, (uint32_t)hv);
-          const uint32_t vteam = (uint32_t)h_team(vfl);
-          const int32_t hp = (int32_t)W::readlane(S.hhp, (uint32_t)hv) - dmg;  // Character::hit CH:242-246
-          W::setlane(S.hhp, (uint32_t)hv, (uint32_t)hp);
-          add_lane(S.hmd, (uint32_t)hv, eff);
-          const bool cross = owner && vteam != owner_team;
-          if (cross) {
-            add_lane(S.hdm, (uint32_t)(owner - 1), dmg);
-            add_lane(S.hef, (uint32_t)(owner - 1), eff);
-          }
-          if (hp <= 0) {
-            W::setlane(S.hfl, (uint32_t)hv, hv == p.ind ? (vfl & ~HF_ALIVE) : (vfl & ~(HF_ALIVE | HF_CTRL | HF_OCC)));
-            if (owner && owner_team == my_team && vteam != my_team) {
-              ++S.tkills, S.loot += 100;
-              if (owner == p.ind + 1) S.loot += 900, ++S.kills;
-            }
-            if (cross) add_lane(S.hk, (uint32_t)(owner - 1), 1);
-          }
-        } else {  // zombie_damage G:574-598
-          const uint32_t zp = W::readlane(S.zpos, (uint32_t)zv);
-          const int32_t hp = (int32_t)W::readlane(S.zhp, (uint32_t)zv) - dmg;
-          W::setlane(S.zhp, (uint32_t)zv, (uint32_t)hp);
-          add_lane(S.zmd, (uint32_t)zv, eff);
-          if (owner) {
-            add_lane(S.hdm, (uint32_t)(owner - 1), dmg);
-            add_lane(S.hef, (uint32_t)(owner - 1), eff);
-          }
-          if (hp <= 0) {
-            W::setlane(S.zpos, (uint32_t)zv, 0u);
-            if (owner && owner_team == my_team) {
-              const int pts = 500 + ((zp & ZF_SUPER) ? 250 : 0);
-              ++S.tkills, S.loot += pts / 10;
-              if (owner == p.ind + 1) S.loot += pts * 9 / 10, ++S.kills;
-            }
-            if (owner) add_lane(S.hk, (uint32_t)(owner - 1), 1);
-          }
-        }
+        hit_one(S, p, my_team, j * 64 + (int)l, hv, zv);
       }
     }
   }
@@ -670,6 +795,8 @@ struct Core {
     const uint32_t r = draw(S, lds, p) & 1u;  // drawn even when no bullet is alive
     if (!any) return;
     uint64_t moved[NB];
+    V nci[NB];
+    P passed[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const P alive = (S.ba[j] & BA_ALIVE) != 0u;
@@ -696,10 +823,25 @@ struct Core {
       }
       const P pass = inb & (temp | ((!wall) & ((!pin) | W::frombits(covered))));
       moved[j] = W::ballot(pass);
+      nci[j] = ci, passed[j] = pass;
       // survivors advance and lose their designation; everything else that was alive dies
       const V na = (S.ba[j] & ~(POS_MASK | BA_REF)) | nq;
       S.ba[j] = W::select(pass, na, V(0u));
       S.bc[j] = W::select(pass, S.bc[j] + 0x10000u, S.bc[j]);
+    }
+    if (!HBM_PLANE) {
+      // every surviving bullet has just entered its cell.  If no two of them entered the same cell (they claim their
+      // cells in a scratch bitmap), each one is its cell's last entrant and is designated, whatever the sweep order
+      uint64_t dup = 0ull;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) dup |= W::ballot(bm_claim(S, p, BM_TMP, nci[j], passed[j]));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bm_clear(S, p, BM_TMP, nci[j], passed[j]);
+      if (!dup) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) S.ba[j] = W::select(passed[j], S.ba[j] | BA_REF, S.ba[j]);
+        return;
+      }
     }
     // designation: r = 1 sweeps slots ascending (last entrant = highest slot), r = 0 descending
 #pragma unroll
@@ -993,12 +1135,34 @@ struct Core {
     const V tfl = W::lds_u8(lds, tci, inb);
     const V ofl = W::lds_u8(lds, oci, live);
     // who is on the target cells; do two humans meet on a cell
-    const uint64_t movers = W::ballot(is_move);
     const uint64_t placers = W::ballot(is_place & inb);
-    const uint64_t needb = W::ballot(inb & (((tfl & SF_CELL_POUT) != 0u) | is_place));
-    uint64_t occH = 0ull, occZ = 0ull, occB = 0ull;
+    const P needb = inb & (((tfl & SF_CELL_POUT) != 0u) | is_place);
+    P oH, oZ, oB;
     bool slow = W::ballot(live & ((ofl & (SF_CELL_PIN_UP | SF_CELL_PIN_DN | SF_CELL_CHEST)) != 0u)) != 0ull;
-    {
+    if (!HBM_PLANE) {
+      // occupants scatter their cells into bitmaps, the acting humans test their target cells.  A fourth bitmap
+      // holds the cells of humans that may walk away in this sweep, then the claims of the targets themselves
+      const P hocc = (S.hfl & HF_OCC) != 0u, zlive = (S.zpos & ZF_ALIVE) != 0u;
+      const V hci = cell_index_v(p, S.hpos), zci = cell_index_v(p, S.zpos);
+      const bool bul = W::ballot(needb) != 0ull;
+      bm_set(S, p, BM_HUM, hci, hocc);
+      bm_set(S, p, BM_ZOM, zci, zlive);
+      if (bul) bm_bullets(S, p, BM_REF, true);
+      bm_set(S, p, BM_TMP, oci, is_move);
+      oH = bm_test(S, p, BM_HUM, tci, inb), oZ = bm_test(S, p, BM_ZOM, tci, inb);
+      oB = needb & bm_test(S, p, BM_REF, tci, needb);
+      const P leaves = inb & bm_test(S, p, BM_TMP, tci, inb);
+      bm_clear(S, p, BM_HUM, hci, hocc);
+      bm_clear(S, p, BM_ZOM, zci, zlive);
+      if (bul) bm_bullets(S, p, BM_REF, false);
+      bm_clear(S, p, BM_TMP, oci, is_move);
+      const P shared = bm_claim(S, p, BM_TMP, tci, inb);
+      bm_clear(S, p, BM_TMP, tci, inb);
+      if (W::ballot(leaves | shared)) slow = true;
+    } else {
+      const uint64_t movers = W::ballot(is_move);
+      const uint64_t needbm = W::ballot(needb);
+      uint64_t occH = 0ull, occZ = 0ull, occB = 0ull;
       uint64_t m = W::ballot(inb);
       while (m) {
         const uint32_t i = (uint32_t)W::ctz64(m);
@@ -1009,12 +1173,12 @@ struct Core {
         const uint64_t same = W::ballot(inb & (tq == q));
         if (hs) occH |= bit;
         if (W::ballot((S.zpos & (ZF_ALIVE | POS_MASK)) == (ZF_ALIVE | q))) occZ |= bit;
-        if ((needb & bit) && refbullet_at(S, q) >= 0) occB |= bit;
+        if ((needbm & bit) && refbullet_at(S, q) >= 0) occB |= bit;
         // the human standing there may move away in this sweep; another human aims at the same cell
         if ((hs & movers) || (same & (same - 1ull))) slow = true;
       }
+      oH = W::frombits(occH), oZ = W::frombits(occZ), oB = W::frombits(occB);
     }
-    const P oH = W::frombits(occH), oZ = W::frombits(occZ), oB = W::frombits(occB);
     const P t_wall = (tfl & SF_CELL_WALL) != 0u, t_pin = (tfl & (SF_CELL_PIN_UP | SF_CELL_PIN_DN)) != 0u;
     // showit() of the target is one of '?', '^', 'v', '.', '*' (G:750-756): not a wall, nobody on it, and not a bare 'O'
     const P bare_out = ((tfl & SF_CELL_POUT) != 0u) & (!t_pin) & ((tfl & SF_CELL_CHEST) == 0u) & (!oB);
@@ -1428,6 +1592,11 @@ struct Core {
     W::copy_g2l(tab + LDS_EXP_BYTES, reinterpret_cast<const uint8_t *>(p.tab->hatab), (uint32_t)(HT_WORDS * 4));
     S.xt = reinterpret_cast<const uint32_t *>(tab);
     S.ht = reinterpret_cast<const uint32_t *>(tab + LDS_EXP_BYTES);
+    S.bm = nullptr;
+    if (!HBM_PLANE) {
+      S.bm = reinterpret_cast<uint32_t *>(lds + LDS_TABLE_BYTES + p.cells_pad);
+      W::lds_zero(S.bm, (uint32_t)(BM_COUNT * p.bm_words));
+    }
     S.la = V(0u);
     S.la2 = V(0u), S.la2_ok = 0u;
     return HBM_PLANE ? p.flags + (size_t)a * (size_t)p.cells_pad : lds + LDS_TABLE_BYTES;

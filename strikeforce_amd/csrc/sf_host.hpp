@@ -216,6 +216,7 @@ struct Env {
     cells = cfg.floors * cfg.rows * cfg.cols;
     p.A = cfg.arenas, p.F = cfg.floors, p.N = cfg.rows, p.M = cfg.cols;
     p.cells = cells, p.cells_pad = (cells + 15) & ~15;
+    p.bm_words = bm_words_for(p.cells_pad);
     p.H = cfg.cap_humans, p.Z = cfg.cap_zombies, p.B = cfg.cap_bullets, p.P = cfg.cap_portals, p.C = cfg.cap_chests;
     p.mode = cfg.mode, p.level = cfg.level, p.n_agents = cfg.n_agents, p.auto_reset = cfg.auto_reset;
     p.reseed = cfg.reseed_stride > 0 ? cfg.reseed_stride : cfg.arenas;

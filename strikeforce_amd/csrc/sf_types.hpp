@@ -96,6 +96,7 @@ struct Tables {
 // ---- everything a kernel needs -----------------------------------------------------------------------
 struct Params {
   int32_t A, F, N, M, cells, cells_pad;
+  int32_t bm_words;  // words per cell bitmap (bm_words_for(cells_pad))
   int32_t H, Z, B, P, C;
   int32_t mode, level, n_agents, auto_reset, reseed, timer_lim, squad_floor;
   int32_t ind;     // the human slot this process plays (`ind`, gameplay.hpp:39); 0 except in Battle matches
@@ -125,10 +126,16 @@ struct Params {
 constexpr int LOGT_OFF = 512;
 constexpr int LOGT_ENTRIES = LOGT_OFF + 65537;
 
+// Per-arena scratch bitmaps in LDS, one bit per cell (sf_core.hpp "cell bitmaps"): only with the flag plane in LDS
+constexpr int BM_COUNT = 4;
+inline int bm_words_for(int cells) { return ((cells + 31) / 32 + 3) & ~3; }  // words per bitmap, 16-byte multiple
+
 inline int nb_for(int B) { return (B + 63) / 64; }
 constexpr int LDS_EXP_BYTES = 2048;                                   // exptab
 constexpr int LDS_TABLE_BYTES = LDS_EXP_BYTES + HT_WORDS * 4;         // exptab, then Tables::hatab
-inline size_t lds_bytes_for(int cells_pad) { return (size_t)cells_pad + LDS_TABLE_BYTES; }
+inline size_t lds_bytes_for(int cells_pad) {
+  return (size_t)cells_pad + LDS_TABLE_BYTES + (size_t)BM_COUNT * 4u * (size_t)bm_words_for(cells_pad);
+}
 // flag planes above this size stay in HBM (Core<.., HBM_PLANE>): staging them would leave < 12 wavefronts per CU
 constexpr int LDS_PLANE_MAX = 12 * 1024;
 inline bool hbm_plane(int cells_pad) { return cells_pad > LDS_PLANE_MAX; }

@@ -89,6 +89,27 @@ struct WaveGfx950 {
   static SF_DEV V shlv(V a, V sh) { return a << sh; }
   static SF_DEV P gts(V a, V b) { return (int32_t)a > (int32_t)b; }  // signed
   static SF_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
+  // cell bitmaps in LDS: OR bits into words (lanes may share a word: LDS atomics), with or without the old value
+  static SF_DEV void lds_or_u32(uint32_t *base, V widx, V bits, P pred) {
+    if (pred) (void)__hip_atomic_fetch_or(base + widx, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_wave_barrier();
+  }
+  static SF_DEV V lds_or_rtn_u32(uint32_t *base, V widx, V bits, P pred) {
+    uint32_t old = 0u;
+    if (pred) old = __hip_atomic_fetch_or(base + widx, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_wave_barrier();
+    return old;
+  }
+  static SF_DEV void lds_store_u32(uint32_t *base, V widx, V val, P pred) {
+    if (pred) base[widx] = val;
+    __builtin_amdgcn_wave_barrier();
+  }
+  static SF_DEV void lds_zero(uint32_t *base, uint32_t nwords) {  // nwords: multiple of 4
+    for (uint32_t off = lane() * 4u; off < nwords; off += 64u * 4u)
+      *reinterpret_cast<u32x4 *>(base + off) = (u32x4)(0u);
+    __builtin_amdgcn_wave_barrier();
+  }
+  static SF_DEV V mad24(V a, uint32_t b, V c) { return __umul24(a, b) + c; }
   // per-lane byte store into the LDS flag plane (distinct cells per lane)
   static SF_DEV void lds_store_u8(uint8_t *lds, V idx, V val, P pred) {
     if (pred) lds[idx] = (uint8_t)val;

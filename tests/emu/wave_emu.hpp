@@ -207,6 +207,30 @@ struct WaveEmu {
     for (int i = 0; i < 64; ++i)
       if ((pred.m >> i) & 1ull) lds[idx.v[i]] = (uint8_t)val.v[i];
   }
+  static void lds_or_u32(uint32_t *base, const V &w, const V &bits, P pred) {
+    EMU_OP();
+    for (int i = 0; i < 64; ++i)
+      if ((pred.m >> i) & 1ull) base[w.v[i]] |= bits.v[i];
+  }
+  static V lds_or_rtn_u32(uint32_t *base, const V &w, const V &bits, P pred) {
+    EMU_OP();
+    V r(0u);
+    for (int i = 0; i < 64; ++i)
+      if ((pred.m >> i) & 1ull) r.v[i] = base[w.v[i]], base[w.v[i]] |= bits.v[i];
+    return r;
+  }
+  static void lds_store_u32(uint32_t *base, const V &w, const V &val, P pred) {
+    EMU_OP();
+    for (int i = 0; i < 64; ++i)
+      if ((pred.m >> i) & 1ull) base[w.v[i]] = val.v[i];
+  }
+  static void lds_zero(uint32_t *base, uint32_t nwords) { memset(base, 0, (size_t)nwords * 4u); }
+  static V mad24(const V &a, uint32_t b, const V &c) {
+    EMU_OP();
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = (a.v[i] & 0xffffffu) * (b & 0xffffffu) + c.v[i];
+    return r;
+  }
   static V mul24(const V &a, const V &b) {  // operands below 2^24, like v_mul_u32_u24
     EMU_OP();
     V r;
