@@ -40,3 +40,34 @@ def test_round_trip_and_replay_is_deterministic(tmp_path):
         runs.append((n, int(sim.digest()[0]), sim.results()[0, 0].tolist()))
     assert runs[0] == runs[1] == runs[2]
     assert runs[0][0] > 50
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_replay_on_the_device_equals_the_oracle(tmp_path):
+    """f-1 on the GPU: a `.sf_sample` is written, read back and replayed through ArenaBatch (HIP kernels); digest,
+    result record and iteration count equal the oracle's replay of the same file (gameplay.hpp:1771-1794,966-969;
+    Character.hpp:570-648).  Two samples: one whose command stream runs out first, one whose episode ends first (a
+    '_' in the stream: obey() sets Hp to 0, gameplay.hpp:696-699, and check_end() stops the loop before the file does)."""
+    from strikeforce_amd import env
+    m, portal = config.synthetic_map(30, 100, portal_pairs=2)
+    a = _sample(100, seed=11)
+    b = _sample(300, seed=12)
+    b.commands = b.commands[:60] + "_" + b.commands[61:]
+    for k, s in enumerate((a, b)):
+        p = tmp_path / ("g%d.sf_sample" % k)
+        replay.write_sample(str(p), s)
+        r = replay.read_sample(str(p))
+        runs = []
+        for impl in (Oracle, env.ArenaBatch):
+            w = replay.workload_for(r, 30, 100, m, portal, H=16, Z=32, B=64)
+            sim = impl(w)
+            n = replay.replay(r, sim)
+            runs.append((n, int(sim.digest()[0]), sim.results()[0, 0].tolist(), int(sim.done()[0])))
+        assert runs[0] == runs[1], (k, runs)
+        if k == 0:
+            assert runs[0][0] == 100 and runs[0][3] == 0, runs[0]   # the command stream ran out, the game goes on
+        else:
+            assert runs[0][3] == 1 and runs[0][0] == 61, runs[0]    # '_' is the 61st command: Hp 0, dead at the loop top that follows
