@@ -421,7 +421,8 @@ struct Core {
     const V ci0 = ((zq >> 20) * (uint32_t)p.N + zr) * (uint32_t)p.M + zc;  // the zombie's own cell index
     const V qn0 = zq + 1024u, qn1 = zq + 1u, qn2 = zq - 1024u, qn3 = zq - 1u;  // DX/DY order: down, right, up, left
     uint64_t skip = 0ull;
-    if (!HBM_PLANE) {
+    const bool use_bm = !HBM_PLANE;
+    if (use_bm) {
       // humans and designated bullets scatter their cells into bitmaps; every zombie tests its own cell (a bullet
       // there: skip) and its four neighbours (a bullet: not '.'; a human: punch)
       const P hocc = (S.hfl & HF_OCC) != 0u;
@@ -489,7 +490,7 @@ struct Core {
           const int rr = r + DX(i1), cc = c + DY(i1);
           if (!inmap(p, rr, cc)) continue;
           const uint32_t q = pos_pack(f, rr, cc);
-          if (!HBM_PLANE || human_at(S, q) >= 0) {
+          if (use_bm || human_at(S, q) >= 0) {
             int index = b_ind(S, p);
             if (refbullet_at(S, q) < 0 && index != -1)  // Zombie::punch CH:838-844
               bullet_put(S, index, q, i1 + 1, zmd > 0 ? zmd : 0, 0, 1, 0);
@@ -528,7 +529,12 @@ struct Core {
       const P plain = act & ((fl & (uint32_t)(SF_CELL_WALL | SF_CELL_PIN_UP | SF_CELL_PIN_DN | SF_CELL_CHEST | SF_CELL_POUT)) ==
                              (uint32_t)SF_CELL_POUT);
       uint64_t need = pm;
-      if (W::ballot(plain)) {
+      const uint64_t plm = W::ballot(plain);
+      if (plm && !(plm & (plm - 1ull))) {  // a single exit: three ballots beat three bitmaps
+        const uint32_t i = (uint32_t)W::ctz64(plm);
+        const uint32_t q = W::readlane(S.ppos, i) & POS_MASK;
+        if (human_at(S, q) < 0 && zombie_at(S, q) < 0 && refbullet_at(S, q) < 0) need &= ~plm;
+      } else if (plm) {
         const P hocc = (S.hfl & HF_OCC) != 0u, zlive = (S.zpos & ZF_ALIVE) != 0u;
         const V hci = cell_index_v(p, S.hpos), zci = cell_index_v(p, S.zpos);
         bm_set(S, p, BM_HUM, hci, hocc);
@@ -751,6 +757,7 @@ struct Core {
 #pragma unroll
       for (int j = 0; j < NB; ++j) any = any || W::ballot((S.ba[j] & BA_REF) != 0u) != 0ull;
       if (!any) return;
+      {
       bm_bullets(S, p, BM_REF, true);
       const P hlive = (S.hfl & HF_ALIVE) != 0u;
       const P zlive = (S.zpos & ZF_ALIVE) != 0u;
@@ -768,6 +775,7 @@ struct Core {
         hit_one(S, p, my_team, refbullet_at(S, W::readlane(S.zpos, i) & POS_MASK), -1, (int)i);
       }
       return;
+      }
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -1111,6 +1119,11 @@ struct Core {
     SF_STAMP(S, 9);
     const uint32_t r = draw(S, lds, p) & 1u;
     if (!alive) {
+      S.hcmd = V((uint32_t)'+');
+      return;
+    }
+    if (!(alive & (alive - 1ull))) {  // one human: nobody to meet, and one obey() costs less than the all-lanes form
+      human_action_serial(S, lds, p, a, alive, r);
       S.hcmd = V((uint32_t)'+');
       return;
     }
