@@ -208,7 +208,11 @@ int sf_results_allgather(sf_env *env, int32_t *d_out);
 /* Make the env's stream (and, with host_too != 0, the calling thread) wait for every gather issued so far. */
 int sf_comm_wait(sf_env *env, int32_t host_too);
 
-/* Replaces the loop exit test `if(check_end()) break;` gameplay.hpp:1450. */
+/* Replaces the loop exit test `if(check_end()) break;` gameplay.hpp:1450.  Without auto_reset: 1 once the arena's
+ * episode has ended (the arena then stands still).  With auto_reset: the number of episodes (saturating at 255) that
+ * ended during the LAST sf_step / sf_step_device call, over all of its k iterations; the arena has already restarted.
+ * The result record (sf_results) is the one of the last episode that ended; a caller that gathers records after
+ * multi-step launches tells fresh from stale ones by this count or by sf_arena_hdr.episodes. */
 int sf_done(sf_env *env, uint8_t *out_host);
 /* The same flag on the device, one byte per (arena, agent) (every agent of an arena gets its arena's flag), in the
  * layout the policy library's reset_memory entry (strikeforce_policy.h) takes: with auto_reset it marks the agents whose game just restarted, i.e. where the

@@ -54,10 +54,13 @@ typedef struct sf_policy sf_policy;
 int sf_policy_create(const sf_policy_weights *w, int32_t max_agents, int32_t device, sf_policy **out);
 void sf_policy_destroy(sf_policy *p);
 
-/* Backbone::reset_memory() (Modules.hpp:95-100) for the agents whose byte in d_mask (device, one per agent) is
- * non-zero; NULL resets every agent.  Call it with the done flags when an arena restarts: the reference
- * builds a new Agent per game (Custom.hpp prepare()). */
+/* Backbone::reset_memory() (Modules.hpp:95-100) for the agents whose byte in d_mask (device) is non-zero; NULL resets
+ * every agent.  Call it with the done flags when an arena restarts: the reference builds a new Agent per game
+ * (Custom.hpp prepare()).  d_mask must hold `max_agents` bytes (the count given to sf_policy_create): every agent of
+ * the policy is looked at.  A caller that runs fewer agents, with a mask of that many bytes (the sf_done_device output
+ * of a smaller env), uses sf_policy_reset_memory_n: only agents [0, agents) are looked at. */
 int sf_policy_reset_memory(sf_policy *p, const uint8_t *d_mask);
+int sf_policy_reset_memory_n(sf_policy *p, const uint8_t *d_mask, int32_t agents);
 
 /* AgentModel::forward (Modules.hpp:106-134,169-178) for agents [0, agents): d_obs is the device buffer of
  * sf_observe_device ([agents][32][31][31] f32); writes d_probs [agents][9] (softmax + 1e-8) and d_value [agents]

@@ -1439,7 +1439,6 @@ struct Core {
 
   // One iteration of the loop body G:1452-1471 followed by the next loop top.
   static SF_DEV void step(Arena &S, uint8_t *lds, const Params &p, int a) {
-    S.ended = 0;
     if (S.done) return;
     // the two half-ticks share `update_tmp; hit_human; hit_zombie; ++frame; update_bull` (G:1457-1463,1465-1471)
     SF_STAMP(S, 0);
@@ -1470,7 +1469,7 @@ struct Core {
     SF_NOUNROLL for (int pass = 0; pass < 2; ++pass) {
       loop_top(S, lds, p, a);
       if (!S.done || pass == 1) break;
-      S.ended = 1;
+      if (S.ended < 255) ++S.ended;  // episodes that ended during this launch (sf_done with auto_reset)
       ++S.episodes;
       if (!p.auto_reset) break;
       const uint64_t tb = (((uint64_t)S.tb_hi << 32) | S.tb_lo) + (uint64_t)(uint32_t)p.reseed;
@@ -1637,6 +1636,7 @@ struct Core {
     // would need, 0.7 % shorter than the 64 steps of 16 per step.  Measured over 4 / 8 / 16 / 32 / 64 draws per step:
     // 16 is the best for long launches (+1.7 % over 4) and for one-step launches (p90 128 -> 28 us).
     S.wrate = 4u;
+    S.ended = 0;
     SF_STAMP_BEGIN(S);
     for (int s = 0; s < k; ++s) {
       const uint8_t *c = cmds + ((size_t)s * (size_t)p.A + (size_t)a) * (size_t)p.n_agents;

@@ -1006,15 +1006,22 @@ int sf_policy_create(const sf_policy_weights *w, int32_t max_agents, int32_t dev
 
 void sf_policy_destroy(sf_policy *p) { delete reinterpret_cast<Policy *>(p); }
 
+int sf_policy_reset_memory_n(sf_policy *pp, const uint8_t *d_mask, int32_t agents) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
+  int rc = sfp::check_agents(p, agents);
+  if (rc) return rc;
+  SFP_HIP(hipSetDevice(p->device));
+  const int n = agents * sfp::HID;
+  hipLaunchKernelGGL(sfp::k_reset_memory, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->h[0], p->h[1],
+                     p->action_input, d_mask, agents);
+  SFP_HIP(hipGetLastError());
+  return SF_OK;
+}
 int sf_policy_reset_memory(sf_policy *pp, const uint8_t *d_mask) {
   Policy *p = reinterpret_cast<Policy *>(pp);
   if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
-  SFP_HIP(hipSetDevice(p->device));
-  const int n = p->max_agents * sfp::HID;
-  hipLaunchKernelGGL(sfp::k_reset_memory, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->h[0], p->h[1],
-                     p->action_input, d_mask, p->max_agents);
-  SFP_HIP(hipGetLastError());
-  return SF_OK;
+  return sf_policy_reset_memory_n(pp, d_mask, p->max_agents);
 }
 
 int sf_policy_forward(sf_policy *pp, const float *d_obs, int32_t agents, float *d_probs, float *d_value) {

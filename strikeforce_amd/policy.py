@@ -77,6 +77,8 @@ def _bind(L):
     L.sf_policy_destroy.argtypes = [vp]
     L.sf_policy_destroy.restype = None
     L.sf_policy_reset_memory.argtypes = [vp, vp]
+    L.sf_policy_reset_memory_n.argtypes = [vp, vp, C.c_int32]
+    L.sf_policy_reset_memory_n.restype = C.c_int
     L.sf_policy_forward.argtypes = [vp, vp, C.c_int32, vp, vp]
     L.sf_policy_act.argtypes = [vp, vp, C.c_int32, C.c_char_p, C.c_uint64, C.c_int32, vp, vp]
     L.sf_policy_get_memory.argtypes = [vp, C.c_int32, _FP, _FP]
@@ -92,7 +94,7 @@ def _bind(L):
 
 
 # every symbol include/strikeforce_policy.h declares
-EXPORTS = ["sf_policy_create", "sf_policy_destroy", "sf_policy_reset_memory", "sf_policy_forward", "sf_policy_act",
+EXPORTS = ["sf_policy_create", "sf_policy_destroy", "sf_policy_reset_memory", "sf_policy_reset_memory_n", "sf_policy_forward", "sf_policy_act",
            "sf_policy_get_memory", "sf_policy_set_memory", "sf_policy_set_stream", "sf_policy_synchronize",
            "sf_policy_kernel_time", "sf_policy_gemm", "sf_policy_abi_version"]
 
@@ -156,9 +158,14 @@ class PolicyBatch:
     def synchronize(self):
         self._ck(self.L.sf_policy_synchronize(self.h), "sf_policy_synchronize")
 
-    def reset_memory(self, d_mask_ptr=None):
-        self._ck(self.L.sf_policy_reset_memory(self.h, C.c_void_p(d_mask_ptr) if d_mask_ptr else None),
-                 "sf_policy_reset_memory")
+    def reset_memory(self, d_mask_ptr=None, agents=None):
+        """d_mask: device bytes, one per agent; with `agents` only agents [0, agents) are looked at (a mask of that
+        many bytes), otherwise the mask must hold max_agents bytes."""
+        m = C.c_void_p(d_mask_ptr) if d_mask_ptr else None
+        if agents is None:
+            self._ck(self.L.sf_policy_reset_memory(self.h, m), "sf_policy_reset_memory")
+        else:
+            self._ck(self.L.sf_policy_reset_memory_n(self.h, m, int(agents)), "sf_policy_reset_memory_n")
 
     def forward(self, d_obs_ptr, agents, d_probs_ptr, d_value_ptr):
         self._ck(self.L.sf_policy_forward(self.h, C.c_void_p(d_obs_ptr), int(agents), C.c_void_p(d_probs_ptr),

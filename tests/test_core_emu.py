@@ -53,3 +53,19 @@ def test_observation_parity_exact():
         assert x.shape == y.shape
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), name
         assert np.count_nonzero(x) > 100
+
+
+def test_done_counts_episodes_over_a_multi_step_launch():
+    """With auto_reset, sf_done reports how many episodes ended during the last call, over all of its k iterations
+    (strikeforce.h): equal on oracle and device source, and equal to the growth of the episode counter."""
+    w = config.baseline_workload("C2", arenas=8)
+    o, e = Oracle(w), Emu(w)
+    tb, sr = w.seeds()
+    o.reset(tb, sr), e.reset(tb, sr)
+    cmds, _ = config.bench_commands(8, 1, 1500)
+    o.step_many(cmds), e.step_many(cmds)
+    eps = np.array([o.dump(a).hdr.episodes for a in range(8)])
+    assert (o.done() == eps).all() and (e.done() == eps).all() and eps.max() >= 2
+    one, _ = config.bench_commands(8, 1, 1)
+    o.step(one[0]), e.step(one[0])
+    assert (o.done() == e.done()).all() and o.done().max() <= 1

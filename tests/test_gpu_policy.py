@@ -102,6 +102,15 @@ def test_reset_memory_mask():
     pb.reset_memory(None)
     h, a = pb.get_memory(1)
     assert not h.any() and a[0] == 1
+    # fewer agents than the policy holds, with a mask of just that many bytes: the tail is neither read nor reset
+    for b in range(B):
+        pb.set_memory(b, rng.normal(size=(2, 160)), np.eye(9)[3])
+    short = _dev(np.array([1, 1, 0], dtype=np.uint8))
+    pb.reset_memory(short.data_ptr(), agents=3)
+    pb.synchronize()
+    for b in range(B):
+        h, a = pb.get_memory(b)
+        assert (not h.any()) == (b in (0, 1)), b
 
 
 def test_sampling_follows_the_predict_distribution():
