@@ -69,6 +69,38 @@ def init_parameters(seed=0, gain=1.0):
     return out
 
 
+def load_checkpoint(path):
+    """Parameters of a trained bot from the reference's checkpoint file: `torch::save(model, dir + "/model.pt")`
+    (bots/bot-0.5/Agent.hpp:77-110,124,159-161) writes a TorchScript module archive whose named_parameters() carry the
+    names AgentModel registered (Modules.hpp:37,62,87-91,147-152) — the names `parameter_shapes()` lists.  Also reads a
+    plain state_dict saved from Python.  Returns {name: float32 numpy array}, every name and shape checked; nothing
+    is filled in silently."""
+    import torch
+    named = None
+    try:
+        m = torch.jit.load(path, map_location="cpu")
+        named = {k: v for k, v in m.named_parameters()}
+    except Exception:  # noqa: BLE001  (not a TorchScript archive)
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+        if hasattr(obj, "state_dict"):
+            obj = obj.state_dict()
+        if not isinstance(obj, dict):
+            raise ValueError("%s holds neither a TorchScript module nor a state_dict" % path)
+        named = obj
+    out = {}
+    for name, shape in parameter_shapes().items():
+        if name not in named:
+            raise ValueError("checkpoint %s lacks parameter %s" % (path, name))
+        a = named[name].detach().to(torch.float32).contiguous().numpy()
+        if a.shape != tuple(shape):
+            raise ValueError("checkpoint parameter %s has shape %s, expected %s" % (name, a.shape, shape))
+        out[name] = a.copy()
+    extra = sorted(k for k in named if k not in out and not k.endswith("num_batches_tracked"))
+    if extra:
+        raise ValueError("checkpoint %s holds parameters this network does not have: %s" % (path, extra[:5]))
+    return out
+
+
 def _bind(L):
     if getattr(L, "_sf_policy_bound", False):
         return

@@ -109,3 +109,40 @@ def test_restatement_reproduces_the_committed_vectors():
         np.testing.assert_allclose(g["probs"], w["probs"], rtol=2e-5, atol=1e-7)
         np.testing.assert_allclose(g["value"], w["value"], rtol=2e-5, atol=1e-7)
         np.testing.assert_allclose(g["h_abs_sum"], w["h_abs_sum"], rtol=2e-5)
+
+
+def test_load_checkpoint_reads_a_torchscript_module_archive_and_a_state_dict(tmp_path):
+    """policy.load_checkpoint on the two file forms a trained bot comes in: the TorchScript module archive that
+    `torch::save(model, ".../model.pt")` writes (Agent.hpp:124; produced here by scripting the restated AgentModel, the
+    same container format) and a Python state_dict.  Names, shapes and values must come back exactly."""
+    import torch
+    from strikeforce_amd import policy
+    params = policy.init_parameters(seed=5)
+    model = policy_ref.model_from_parameters(params)
+
+    class Node(torch.nn.Module):  # a scriptable module tree with the same parameter names (what the C++ side registers)
+        def forward(self, x: torch.Tensor) -> torch.Tensor:
+            return x
+
+    root = Node()
+    for name, value in params.items():
+        node, parts = root, name.split(".")
+        for part in parts[:-1]:
+            if not hasattr(node, part):
+                node.add_module(part, Node())
+            node = getattr(node, part)
+        node.register_parameter(parts[-1], torch.nn.Parameter(torch.from_numpy(value.copy())))
+    ts = tmp_path / "model.pt"
+    torch.jit.save(torch.jit.script(root), str(ts))
+    got = policy.load_checkpoint(str(ts))
+    assert set(got) == set(params)
+    assert all(np.array_equal(got[k], params[k]) for k in params)
+    sd = tmp_path / "state.pt"
+    torch.save(model.state_dict(), str(sd))
+    got = policy.load_checkpoint(str(sd))
+    assert all(np.array_equal(got[k], params[k]) for k in params)
+    bad = dict(model.state_dict())
+    bad.pop("value.1.bias")
+    torch.save(bad, str(tmp_path / "bad.pt"))
+    with pytest.raises(ValueError):
+        policy.load_checkpoint(str(tmp_path / "bad.pt"))
