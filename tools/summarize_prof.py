@@ -24,6 +24,7 @@ class glob:  # gpurun merges every call's outputs into gpurun_out/: only the new
         return files[-1:]
 
 tag, workload, arenas, kpl = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+timed = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # launches of the bench's timed region (the last ones of that length)
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -45,6 +46,10 @@ for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
     big = [x for x in d if x > 0.5 * max(d)] if d else []
     summary = {"k_step_dispatches": len(d), "k_step_K%d_dispatches" % kpl: len(big),
                "k_step_K%d_avg_ms" % kpl: sum(big) / len(big) / 1e6 if big else None,
+               # the bench's timed region = the last `timed` launches of that length (the earlier ones are the untimed
+               # pre-roll and warm-up, with populations still growing): this is the figure bench.py's HIP events give
+               "k_step_K%d_timed_launches" % kpl: timed or None,
+               "k_step_K%d_timed_avg_ms" % kpl: (sum(big[-timed:]) / timed / 1e6) if (timed and len(big) >= timed) else None,
                "k_observe_avg_ms": (lambda o: sum(o) / len(o) / 1e6 if o else None)(
                    [r["Duration_Ns"] for r in keep if "k_observe" in r["Kernel_Name"]])}
     json.dump(summary, open(os.path.join(dst, tag + "_kernel_summary.json"), "w"), indent=1)
@@ -52,7 +57,10 @@ for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
 
 pmc = {}
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    for f in glob.glob(os.path.join(src, "pmc_" + kind, "*", "*_counter_collection.csv")):
+    pats = [os.path.join(src, "pmc_%s_%d" % (kind, kpl), "*", "*_counter_collection.csv"),
+            os.path.join(src, "pmc_" + kind, "*", "*_counter_collection.csv")]
+    files = glob.glob(pats[0]) or glob.glob(pats[1])
+    for f in files:
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
                 if "k_step" in r["Kernel_Name"] and r["Counter_Name"] == counter]
         if vals:
