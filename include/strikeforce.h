@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 1
+#define SF_ABI_VERSION 2
 
 /* Observation geometry — bots/bot-0.5/Custom.hpp:137-159 (32 channels, 31x31 window). */
 #define SF_OBS_CHANNELS 32
@@ -109,6 +109,12 @@ typedef struct sf_config {
   sf_profile player;        /* profile of every commanded human (Character::me) */
   sf_profile npc;           /* character/human_enemy.txt */
   sf_items items;
+  /* ABI 2: one character record per commanded human, as the players of a lock-step match exchange them before the
+   * first tick (give_info / get_info gameplay.hpp:120-151; blob = Human::log_file / scan_file Character.hpp:570-648).
+   * 0: every commanded human is built from `player`; n_agents: commanded human i is built from agent_profile[i]
+   * (and `player` is unused).  NPC humans always come from `npc`. */
+  int32_t n_agent_profiles;
+  sf_profile agent_profile[SF_MAX_AGENTS];
 } sf_config;
 
 typedef struct sf_env sf_env; /* opaque; one per GPU */

@@ -5,7 +5,7 @@ are used by ``tests/`` to talk to the CPU oracle, which exports the same calls w
 """
 import ctypes as C
 
-SF_ABI_VERSION = 1
+SF_ABI_VERSION = 2
 OBS_CHANNELS = 32
 OBS_WINDOW = 31
 OBS_FLOATS = OBS_CHANNELS * OBS_WINDOW * OBS_WINDOW  # 30752, bots/bot-0.5/Custom.hpp:137-159
@@ -91,6 +91,8 @@ class Config(C.Structure):
         ("player", Profile),
         ("npc", Profile),
         ("items", Items),
+        ("n_agent_profiles", C.c_int32),
+        ("agent_profile", Profile * MAX_AGENTS),
     ]
 
 

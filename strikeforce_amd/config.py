@@ -181,7 +181,7 @@ class Workload:
 
 def make_config(arenas, rows, cols, floors=1, H=1, Z=16, B=32, P=8, chests=9000, mode=abi.MODE_SOLO, level=1,
                 n_agents=1, teams=None, auto_reset=1, player_tokens=None, npc_tokens=None, device=0,
-                timer_frames=0, reseed_stride=0, ind=0):
+                timer_frames=0, reseed_stride=0, ind=0, agent_tokens=None):
     cfg = abi.Config()
     cfg.abi_version = abi.SF_ABI_VERSION
     cfg.arenas = arenas
@@ -198,6 +198,13 @@ def make_config(arenas, rows, cols, floors=1, H=1, Z=16, B=32, P=8, chests=9000,
     cfg.player = abi.Profile.from_tokens(player_tokens or HUMAN_ENEMY_TOKENS)
     cfg.npc = abi.Profile.from_tokens(npc_tokens or HUMAN_ENEMY_TOKENS)
     cfg.items = default_items()
+    cfg.n_agent_profiles = 0
+    if agent_tokens is not None:  # one character record per commanded human (a lock-step match's account blobs)
+        if len(agent_tokens) != n_agents:
+            raise ValueError("agent_tokens must hold one record per commanded human")
+        cfg.n_agent_profiles = n_agents
+        for i, t in enumerate(agent_tokens):
+            cfg.agent_profile[i] = abi.Profile.from_tokens(t)
     return cfg
 
 
@@ -223,6 +230,16 @@ def baseline_workload(which, arenas=None, device=0, auto_reset=1):
         cfg = make_config(arenas or 4096, 256, 256, H=8, Z=56, B=128, P=16, mode=abi.MODE_BATTLE, n_agents=8,
                           teams=list(range(1, 9)), device=device, auto_reset=auto_reset)
         m, p = synthetic_map(256, 256, portal_pairs=2)
+    elif which == "KITS":  # Battle match whose players bring different character records (ABI 2: sf_config.agent_profile):
+        # the fresh character/human.txt, the armed human_enemy.txt, a levelled-up account, and a player with level-3 guns
+        rich = [15000, 1000, 15000, 10, 10, 10, 300000, 60, 0, 0, 0, 1, 1, 1, 34] + [1] * 16 + [56]
+        guns = list(HUMAN_ENEMY_TOKENS)
+        guns[23:31] = [3, 0, 2, 0, 3, 1, 0, 2]
+        recs = [HUMAN_TOKENS, HUMAN_ENEMY_TOKENS, rich, guns]
+        cfg = make_config(arenas or 2, 40, 40, H=12, Z=12, B=64, P=8, mode=abi.MODE_BATTLE, n_agents=6,
+                          teams=[1, 2, 3, 1, 2, 3], device=device, auto_reset=auto_reset,
+                          agent_tokens=[recs[i % 4] for i in range(6)])
+        m, p = synthetic_map(40, 40, wall_p=0.05, portal_pairs=1)
     elif which == "MAXCAP":  # every slot pool at the device kernels' maximum (64/64/256/64), 16 commanded humans
         cfg = make_config(arenas or 2, 48, 48, H=64, Z=64, B=256, P=64, mode=abi.MODE_BATTLE, n_agents=16,
                           teams=[1 + (i % 3) for i in range(16)], device=device, auto_reset=auto_reset)

@@ -106,11 +106,11 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   __shared__ uint32_t cmask[OBS_CLASS_RECS];  // non-zero channels of each class record
   __shared__ uint16_t work[OBS_REC_MAX];      // window cell of record r (r >= OBS_CLASS_RECS)
   __shared__ float t_in[16], t_out[16];       // Tables::obs_in / obs_out (obs_in[0] == 1.0)
-  // the leading part of Tables that obs_cell_emit reads through ObsView::tab (der[2], cons_items): an LDS copy, so
-  // that the one lane describing a human cell does not walk four dependent L2 loads in get_damage_effect
-  constexpr int TAB_WORDS = (int)((sizeof(Derived) * 2 + sizeof(int32_t) * 12) / 4);
-  __shared__ uint32_t tab_lds[TAB_WORDS];
-  static_assert(offsetof(Tables, der) == 0 && offsetof(Tables, cons_items) == sizeof(Derived) * 2,
+  // the leading part of Tables that obs_cell_emit reads through ObsView::tab (cons_items, then the used blocks of
+  // der[]): an LDS copy (behind the entity tables in the dynamic allocation), so that the one lane describing a human
+  // cell does not walk four dependent L2 loads in get_damage_effect
+  const int TAB_WORDS = (int)((sizeof(int32_t) * 12 + sizeof(Derived) * (size_t)(p.npc_block + 1)) / 4);
+  static_assert(offsetof(Tables, cons_items) == 0 && offsetof(Tables, der) == sizeof(int32_t) * 12,
                 "obs_cell_emit's tables must lead Tables");
   __shared__ uint32_t list_n, rec_n, spill_n;
   const int a = (int)blockIdx.x / p.n_agents, g = (int)blockIdx.x % p.n_agents;
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
     return;
   }
   const int nh = HW_WORDS * p.H, nz = ZW_WORDS * p.Z, nb = BW_WORDS * p.B;
+  uint32_t *tab_lds = ent + nh + nz + nb;
   for (int i = tid; i < nh; i += OBS_THREADS) ent[i] = gptr(p.hum)[((size_t)(i / p.H) * p.A + a) * p.H + i % p.H];
   for (int i = tid; i < nz; i += OBS_THREADS) ent[nh + i] = gptr(p.zom)[((size_t)(i / p.Z) * p.A + a) * p.Z + i % p.Z];
   for (int i = tid; i < nb; i += OBS_THREADS)
@@ -366,11 +367,11 @@ struct HipRT {
   template <int NB>
   int do_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
     if (hbm_plane(p.cells_pad)) {
-      hipLaunchKernelGGL((k_reset<NB, true>), dim3((unsigned)p.A), dim3(64), (size_t)LDS_TABLE_BYTES, stream, p, tb, serial);
+      hipLaunchKernelGGL((k_reset<NB, true>), dim3((unsigned)p.A), dim3(64), (size_t)p.lds_tab, stream, p, tb, serial);
     } else {
-      int rc = lds_attr(k_reset<NB, false>, lds_bytes_for(p.cells_pad));
+      int rc = lds_attr(k_reset<NB, false>, lds_bytes_for(p.cells_pad, p.lds_tab));
       if (rc) return rc;
-      hipLaunchKernelGGL((k_reset<NB, false>), dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad), stream, p, tb, serial);
+      hipLaunchKernelGGL((k_reset<NB, false>), dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad, p.lds_tab), stream, p, tb, serial);
     }
     SF_HIP(hipGetLastError());
     return SF_OK;
@@ -389,7 +390,7 @@ struct HipRT {
   int do_step(const Params &p, const uint8_t *cmds, int k) {
     const bool hp = hbm_plane(p.cells_pad);
     if (!hp) {
-      int rc = lds_attr(k_step<NB, false>, lds_bytes_for(p.cells_pad));
+      int rc = lds_attr(k_step<NB, false>, lds_bytes_for(p.cells_pad, p.lds_tab));
       if (rc) return rc;
     }
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
@@ -404,9 +405,9 @@ struct HipRT {
       SF_HIP(hipEventRecord(ev->first, stream));
     }
     if (hp)
-      hipLaunchKernelGGL((k_step<NB, true>), dim3((unsigned)p.A), dim3(64), (size_t)LDS_TABLE_BYTES, stream, p, cmds, k);
+      hipLaunchKernelGGL((k_step<NB, true>), dim3((unsigned)p.A), dim3(64), (size_t)p.lds_tab, stream, p, cmds, k);
     else
-      hipLaunchKernelGGL((k_step<NB, false>), dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad), stream, p, cmds, k);
+      hipLaunchKernelGGL((k_step<NB, false>), dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad, p.lds_tab), stream, p, cmds, k);
     SF_HIP(hipGetLastError());
     if (ev) SF_HIP(hipEventRecord(ev->second, stream));
     return SF_OK;
@@ -430,7 +431,9 @@ struct HipRT {
   int launch_observe(const Params &p, int, float *out, uint32_t *nzprev, int mode) {
     SF_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(k_observe, dim3((unsigned)(p.A * p.n_agents)), dim3(OBS_THREADS),
-                       (size_t)(HW_WORDS * p.H + ZW_WORDS * p.Z + BW_WORDS * p.B) * sizeof(uint32_t), stream, p, out, nzprev, mode);
+                       (size_t)(HW_WORDS * p.H + ZW_WORDS * p.Z + BW_WORDS * p.B) * sizeof(uint32_t) + sizeof(int32_t) * 12 +
+                           sizeof(Derived) * (size_t)(p.npc_block + 1),
+                       stream, p, out, nzprev, mode);
     SF_HIP(hipGetLastError());
     return SF_OK;
   }

@@ -307,7 +307,8 @@ struct Core {
   static SF_DEV int h_team(uint32_t fl) { return (int)((fl >> HF_TEAM_SH) & 255u); }
   static SF_DEV int h_vec(uint32_t fl) { return (int)((fl >> HF_VEC_SH) & 3u) - 1; }
   static SF_DEV int h_sel(uint32_t fl) { return (int)((fl >> HF_IND_SH) & 15u) - 1; }
-  static SF_DEV int h_prof(uint32_t fl) { return (fl & HF_PROF) ? 1 : 0; }
+  // the table block of the record this human was built from: the NPC record, or the commanded human's own
+  static SF_DEV int h_block(const Params &p, uint32_t fl) { return (fl & HF_PROF) ? p.npc_block : (int)((fl >> HF_AGP_SH) & 15u); }
   static SF_DEV uint32_t set_vec_sel(uint32_t fl, int vec, int sel) {
     fl &= ~((3u << HF_VEC_SH) | (15u << HF_IND_SH));
     return fl | ((uint32_t)(vec + 1) << HF_VEC_SH) | ((uint32_t)(sel + 1) << HF_IND_SH);
@@ -332,9 +333,11 @@ struct Core {
   }
 
   // Build a fresh human of profile `prof` in slot i (Human::build CH:650-709 / gen_human CH:873-888).
+  // prof 1: the NPC record; prof 0: a commanded human's record (agent record `agp` when every agent has its own)
   static SF_DEV void human_make(Arena &S, const Params &p, uint32_t i, int prof, uint32_t q, int way, int team,
-                                uint32_t extra_flags) {
-    const Derived &d = p.tab->der[prof];
+                                uint32_t extra_flags, int agp = 0) {
+    const Derived &d = p.tab->der[prof ? p.npc_block : agp];
+    extra_flags |= prof ? 0u : ((uint32_t)agp << HF_AGP_SH);
     W::setlane(S.hpos, i, q);
     uint32_t fl = (uint32_t)way | ((uint32_t)team << HF_TEAM_SH) | HF_ALIVE | HF_OCC | (prof ? HF_PROF : 0u) | extra_flags;
     W::setlane(S.hfl, i, set_vec_sel(fl, -1, -1));
@@ -987,7 +990,7 @@ struct Core {
     }
     if ((k = (c == 'c' ? 0 : c == 'v' ? 1 : c == 'b' ? 2 : c == 'n' ? 3 : c == 'm' ? 4 : c == ',' ? 5 : c == '.' ? 6
                                                                                               : c == '/' ? 7 : -1)) >= 0) {
-      if (p.tab->der[h_prof(fl0)].weapon_lvl[k]) W::setlane(S.hfl, i, set_vec_sel(fl0, 2, k));
+      if (p.tab->der[h_block(p, fl0)].weapon_lvl[k]) W::setlane(S.hfl, i, set_vec_sel(fl0, 2, k));
       return;
     }
     const int vec = h_vec(fl0), sel = h_sel(fl0);
@@ -1007,7 +1010,7 @@ struct Core {
       const int rr = r + DX(way - 1), cc = cc0 + DY(way - 1);
       const int index = b_ind(S, p);
       if (index == -1 || !inmap(p, rr, cc)) return;
-      const Derived &d = p.tab->der[h_prof(fl0)];
+      const Derived &d = p.tab->der[h_block(p, fl0)];
       const int32_t md = (int32_t)W::readlane(S.hmd, i);
       const int32_t st = (int32_t)W::readlane(S.hst, i);
       bool can;
@@ -1214,7 +1217,8 @@ struct Core {
       return;
     }
     // ---- the sweep, all humans at once -------------------------------------------------------------------------
-    const V prof_base = W::select((S.hfl & HF_PROF) != 0u, V((uint32_t)(HT_PROF + HT_PROF_STRIDE)), V((uint32_t)HT_PROF));
+    const V prof_base = W::select((S.hfl & HF_PROF) != 0u, V((uint32_t)(HT_PROF + HT_PROF_STRIDE * p.npc_block)),
+                                  W::mad24((S.hfl >> HF_AGP_SH) & 15u, (uint32_t)HT_PROF_STRIDE, V((uint32_t)HT_PROF)));
     const V vec1 = (S.hfl >> HF_VEC_SH) & 3u;          // backpack.vec + 1
     const V sel = ((S.hfl >> HF_IND_SH) & 15u) - 1u;   // backpack.ind (0xffffffff: none)
     V nfl = S.hfl;
@@ -1418,7 +1422,8 @@ struct Core {
         q = i == 0 ? pos_pack(0, 3, 1) : pos_pack(i < 5 ? 0 : p.squad_floor, 1, i + 1);
         fl = (i == 0 || i < p.n_agents) ? HF_CTRL : 0u;  // USE_AGENT_IN_SQUAD_NPCS G:1883-1885
       }
-      human_make(S, p, (uint32_t)i, prof, q, 1, team, fl);
+      // every commanded human of a Battle match is built from its own record when the match brought them
+      human_make(S, p, (uint32_t)i, prof, q, 1, team, fl, (p.mode == SF_MODE_BATTLE && p.npc_block > 1) ? i : 0);
     }
     if (p.mode == SF_MODE_BATTLE) {
       S.hfl = S.hfl & ~HF_OCC;  // not on the map until placed
@@ -1601,17 +1606,17 @@ struct Core {
   static SF_DEV uint8_t *tables(Arena &S, uint8_t *lds, const Params &p, int a) {
     uint8_t *tab = lds;
     W::copy_g2l(tab, reinterpret_cast<const uint8_t *>(p.exptab), (uint32_t)LDS_EXP_BYTES);
-    W::copy_g2l(tab + LDS_EXP_BYTES, reinterpret_cast<const uint8_t *>(p.tab->hatab), (uint32_t)(HT_WORDS * 4));
+    W::copy_g2l(tab + LDS_EXP_BYTES, reinterpret_cast<const uint8_t *>(p.tab->hatab), (uint32_t)p.ht_bytes);
     S.xt = reinterpret_cast<const uint32_t *>(tab);
     S.ht = reinterpret_cast<const uint32_t *>(tab + LDS_EXP_BYTES);
     S.bm = nullptr;
     if (!HBM_PLANE) {
-      S.bm = reinterpret_cast<uint32_t *>(lds + LDS_TABLE_BYTES + p.cells_pad);
+      S.bm = reinterpret_cast<uint32_t *>(lds + p.lds_tab + p.cells_pad);
       W::lds_zero(S.bm, (uint32_t)(BM_COUNT * p.bm_words));
     }
     S.la = V(0u);
     S.la2 = V(0u), S.la2_ok = 0u;
-    return HBM_PLANE ? p.flags + (size_t)a * (size_t)p.cells_pad : lds + LDS_TABLE_BYTES;
+    return HBM_PLANE ? p.flags + (size_t)a * (size_t)p.cells_pad : lds + p.lds_tab;
   }
 
   static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial) {

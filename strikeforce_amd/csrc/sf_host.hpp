@@ -86,7 +86,7 @@ inline void finish_derived(Derived &d) {
 
 // Tables::hatab (sf_types.hpp HT_*): obey()'s key classes (gameplay.hpp:695-821) and the per-profile stats its
 // shooting / selection branches read, as one flat table that the step kernel keeps in LDS
-inline void fill_hatab(Tables &t) {
+inline void fill_hatab(Tables &t, int blocks) {
   memset(t.hatab, 0, sizeof t.hatab);
   uint8_t *cmd = reinterpret_cast<uint8_t *>(t.hatab + HT_CMD);
   auto put = [&](char c, int cls, int prm) { cmd[(unsigned char)c] = (uint8_t)(cls | (prm << 4)); };
@@ -96,7 +96,7 @@ inline void fill_hatab(Tables &t) {
   for (int k = 0; k < 4; ++k) put(selc[k], CL_SELC, k), put(selt[k], CL_SELT, k);
   for (int k = 0; k < 8; ++k) put(selw[k], CL_SELW, k);
   put('u', CL_USE, 0), put('z', CL_PUNCH, 0), put('x', CL_FIRE, 0);
-  for (int pr = 0; pr < 2; ++pr) {
+  for (int pr = 0; pr < blocks; ++pr) {
     uint32_t *w = t.hatab + HT_PROF + pr * HT_PROF_STRIDE;
     const Derived &d = t.der[pr];
     w[HT_P_CDPUNCH] = (uint32_t)d.cd_punch;
@@ -135,8 +135,11 @@ inline int validate(const sf_config *c) {
     return fail(SF_ERR_ARG, "Squad needs cap_humans >= 10 and a map of at least 5 x 12");
   if ((c->mode == SF_MODE_SOLO || c->mode == SF_MODE_TIMER) && c->n_agents != 1)
     return fail(SF_ERR_ARG, "Solo/Timer have exactly one agent");
-  const sf_profile *pr[2] = {&c->player, &c->npc};
-  for (int k = 0; k < 2; ++k) {
+  if (c->n_agent_profiles != 0 && c->n_agent_profiles != c->n_agents)
+    return fail(SF_ERR_ARG, "n_agent_profiles must be 0 or n_agents");
+  const sf_profile *pr[2 + SF_MAX_AGENTS] = {&c->player, &c->npc};
+  for (int i = 0; i < c->n_agent_profiles; ++i) pr[2 + i] = &c->agent_profile[i];
+  for (int k = 0; k < 2 + c->n_agent_profiles; ++k) {
     for (int i = 0; i < 4; ++i)
       if (pr[k]->cons[i] < 0 || pr[k]->cons[i] > 65535 || pr[k]->throw_lvl_cnt[i][1] < 0 ||
           pr[k]->throw_lvl_cnt[i][1] > 65535)
@@ -224,16 +227,20 @@ struct Env {
     p.squad_floor = cfg.floors > 2 ? 2 : cfg.floors - 1;
     p.ind = cfg.ind;
     NB = nb_for(p.B);
-    if (!hbm_plane(p.cells_pad) && lds_bytes_for(p.cells_pad) > rt.max_lds())
+    // tables: one shared player record (block 0) + npc (block 1), or one record per commanded human (blocks 0..15,
+    // the account blobs of a lock-step match, gameplay.hpp:120-151) + npc (block 16)
+    p.npc_block = cfg.n_agent_profiles > 0 ? MAX_PROFILE_BLOCKS - 1 : 1;
+    p.ht_bytes = ht_bytes_for(p.npc_block + 1), p.lds_tab = lds_tab_for(p.npc_block + 1);
+    if (!hbm_plane(p.cells_pad) && lds_bytes_for(p.cells_pad, p.lds_tab) > rt.max_lds())
       return fail(SF_ERR_ARG, "map does not fit the LDS flag plane");
-    // tables
-    derive_profile(cfg, cfg.player, tab.der[0]);
-    derive_profile(cfg, cfg.npc, tab.der[1]);
-    tab.der[1].mindamage_def += 15 * (cfg.level - 1);  // gen_human Character.hpp:882-886
-    finish_derived(tab.der[0]), finish_derived(tab.der[1]);
+    for (int i = 0; i < p.npc_block; ++i)
+      derive_profile(cfg, (cfg.n_agent_profiles > 0 && i < cfg.n_agent_profiles) ? cfg.agent_profile[i] : cfg.player, tab.der[i]);
+    derive_profile(cfg, cfg.npc, tab.der[p.npc_block]);
+    tab.der[p.npc_block].mindamage_def += 15 * (cfg.level - 1);  // gen_human Character.hpp:882-886
+    for (int i = 0; i <= p.npc_block; ++i) finish_derived(tab.der[i]);
     for (int i = 0; i < 4; ++i)
       for (int k = 0; k < 3; ++k) tab.cons_items[i][k] = cfg.items.cons[i][k];
-    fill_hatab(tab);
+    fill_hatab(tab, p.npc_block + 1);
     for (int i = 0; i < SF_MAX_AGENTS; ++i) {
       if (cfg.agent_team[i] < 0 || cfg.agent_team[i] > 255) return fail(SF_ERR_ARG, "agent_team must be 0..255");
       tab.teams[i] = cfg.agent_team[i];

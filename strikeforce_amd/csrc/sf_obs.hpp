@@ -17,8 +17,9 @@ struct ObsView {  // read-only view of one arena's entity tables
   const uint32_t *hum_, *zom_, *bul_;
   const Tables *tab;
   int A, H, Z, B, a;
+  int npc_block;  // Params::npc_block: which table block holds the NPC record
   SF_HD ObsView(const Params &p, int arena)
-      : hum_(p.hum), zom_(p.zom), bul_(p.bul), tab(p.tab), A(p.A), H(p.H), Z(p.Z), B(p.B), a(arena) {}
+      : hum_(p.hum), zom_(p.zom), bul_(p.bul), tab(p.tab), A(p.A), H(p.H), Z(p.Z), B(p.B), a(arena), npc_block(p.npc_block) {}
   SF_HD uint32_t hum(int f, int i) const { return hum_[((size_t)f * A + a) * H + i]; }
   SF_HD uint32_t zom(int f, int i) const { return zom_[((size_t)f * A + a) * Z + i]; }
   SF_HD uint32_t bul(int f, int i) const { return bul_[((size_t)f * A + a) * B + i]; }
@@ -97,7 +98,7 @@ SF_HD inline void obs_cell_emit(const ObsView &v, uint32_t fl, int32_t cdmg, uin
     emit(14, (float)(((hb >> 16) & 255u) != 0u));
     emit(20 + (int)(hf & HF_WAY_MASK) - 1, 1.f);
     int v0, v1;
-    obs_damage_effect(v.tab->der[(hf & HF_PROF) ? 1 : 0], hf, (int32_t)v.hum(HW_STAMINA, h),
+    obs_damage_effect(v.tab->der[(hf & HF_PROF) ? v.npc_block : (int)((hf >> HF_AGP_SH) & 15u)], hf, (int32_t)v.hum(HW_STAMINA, h),
                       (int32_t)v.hum(HW_MINDAMAGE, h), v0, v1);
     emit(24, (float)(v0 / 1000.0)), emit(25, (float)(-v1 / 1000.0));
     emit(26, (float)((int32_t)v.hum(HW_STAMINA, h) / 1000.0));

@@ -40,6 +40,7 @@ constexpr uint32_t HF_CTRL = 1u << 15;        // active_agent: commanded through
 constexpr int HF_VEC_SH = 16;                 // 2 bits: backpack.vec + 1
 constexpr int HF_IND_SH = 18;                 // 4 bits: backpack.ind + 1
 constexpr uint32_t HF_OCC = 1u << 22;         // the cell's s[0] designates this human (alive, or dead `ind`)
+constexpr int HF_AGP_SH = 23;                 // 4 bits: which agent record a commanded human was built from (HF_PROF clear)
 // HW_BPK: blocks | portals << 8 | (portal_ind + 1) << 16
 
 // ---- zombie record: 3 dwords -----------------------------------------------------------------------
@@ -74,15 +75,18 @@ struct Derived {
 
 // ---- human_action's decode / stat table, staged in LDS (sf_core.hpp human_action) ------------------------------
 // words: [HT_CMD .. +32)   128 bytes: command char -> class | param << 4 (obey's key classes, gameplay.hpp:695-821)
-//        [HT_PROF + 72 prof .. ): cd_punch, weapon_lvl[8], cd_weapon[8], weapon[8][4], thr[4][4]   (Derived)
 //        [HT_CONS .. +12)  cons_items[4][3]
-enum { HT_CMD = 0, HT_PROF = 32, HT_PROF_STRIDE = 72, HT_P_CDPUNCH = 0, HT_P_WLVL = 1, HT_P_CDW = 9, HT_P_WEAPON = 17,
-       HT_P_THR = 49, HT_CONS = HT_PROF + 2 * HT_PROF_STRIDE, HT_WORDS = 256 };
+//        [HT_PROF + 72 block .. ): cd_punch, weapon_lvl[8], cd_weapon[8], weapon[8][4], thr[4][4]   (Derived)
+//        blocks: one per character record.  One shared player record: block 0 = player, block 1 = npc.  One record per
+//        commanded human (sf_config.agent_profile): blocks 0..15 = agents, block 16 = npc.  Params::npc_block says which.
+enum { HT_CMD = 0, HT_CONS = 32, HT_PROF = 44, HT_PROF_STRIDE = 72, HT_P_CDPUNCH = 0, HT_P_WLVL = 1, HT_P_CDW = 9,
+       HT_P_WEAPON = 17, HT_P_THR = 49, MAX_PROFILE_BLOCKS = 17, HT_WORDS_MAX = HT_PROF + MAX_PROFILE_BLOCKS * HT_PROF_STRIDE };
+inline int ht_bytes_for(int blocks) { return ((HT_PROF + blocks * HT_PROF_STRIDE) * 4 + 15) & ~15; }
 enum { CL_NOP = 0, CL_SUICIDE, CL_BLOCK, CL_PORTAL, CL_TURN, CL_MOVE, CL_SELC, CL_SELT, CL_SELW, CL_USE, CL_PUNCH, CL_FIRE };
 
 struct Tables {
-  Derived der[2];
   int32_t cons_items[4][3];  // stamina, Hp, effect
+  Derived der[MAX_PROFILE_BLOCKS];  // by block: see HT_* (blocks above npc_block are unused)
   int32_t teams[16];         // BATTLE mode team of agent i
   int32_t obs_n;             // observation fast map: obs_out[i] = obs_map(obs_in[i]), filled on the host
   float obs_in[16], obs_out[16];
@@ -90,7 +94,7 @@ struct Tables {
   // nothing on them) and which of their features are non-zero: the same for every arena and every call
   float class_rec[8][32];
   uint32_t class_mask[8];
-  uint32_t hatab[HT_WORDS];  // see HT_* above; copied to LDS by every step launch
+  uint32_t hatab[HT_WORDS_MAX];  // see HT_* above; the used part (Params::ht_bytes) is copied to LDS by every launch
 };
 
 // ---- everything a kernel needs -----------------------------------------------------------------------
@@ -100,6 +104,9 @@ struct Params {
   int32_t H, Z, B, P, C;
   int32_t mode, level, n_agents, auto_reset, reseed, timer_lim, squad_floor;
   int32_t ind;     // the human slot this process plays (`ind`, gameplay.hpp:39); 0 except in Battle matches
+  int32_t npc_block;  // table block of the NPC record: 1 (one shared player record in block 0) or 16 (one per agent)
+  int32_t ht_bytes;   // used bytes of Tables::hatab
+  int32_t lds_tab;    // bytes of [exptab][hatab] at the start of LDS: the flag plane follows
   const Tables *tab;
   uint32_t *hum;   // [HW_WORDS][A][H]
   uint32_t *zom;   // [ZW_WORDS][A][Z]
@@ -131,10 +138,10 @@ constexpr int BM_COUNT = 4;
 inline int bm_words_for(int cells) { return ((cells + 31) / 32 + 3) & ~3; }  // words per bitmap, 16-byte multiple
 
 inline int nb_for(int B) { return (B + 63) / 64; }
-constexpr int LDS_EXP_BYTES = 2048;                                   // exptab
-constexpr int LDS_TABLE_BYTES = LDS_EXP_BYTES + HT_WORDS * 4;         // exptab, then Tables::hatab
-inline size_t lds_bytes_for(int cells_pad) {
-  return (size_t)cells_pad + LDS_TABLE_BYTES + (size_t)BM_COUNT * 4u * (size_t)bm_words_for(cells_pad);
+constexpr int LDS_EXP_BYTES = 2048;                                   // exptab, then Tables::hatab (Params::lds_tab)
+inline int lds_tab_for(int blocks) { return LDS_EXP_BYTES + ht_bytes_for(blocks); }
+inline size_t lds_bytes_for(int cells_pad, int lds_tab) {
+  return (size_t)cells_pad + (size_t)lds_tab + (size_t)BM_COUNT * 4u * (size_t)bm_words_for(cells_pad);
 }
 // flag planes above this size stay in HBM (Core<.., HBM_PLANE>): staging them would leave < 12 wavefronts per CU
 constexpr int LDS_PLANE_MAX = 12 * 1024;

@@ -77,20 +77,22 @@ class MatchClient:
         self._send_cstr(format_blob(self.name, self.tokens))
         self.teams = [0] * self.n
         self.teams[self.ind] = self.team
+        self.records = [None] * self.n  # every player's character record (get_info, gameplay.hpp:120-151)
+        self.records[self.ind] = list(self.tokens)
         for i in range(self.n):
             if i == self.ind:
                 continue
             _, tok = parse_blob(self._recv_cstr())
             self.teams[i] = int(self._recv_cstr())
-            if tok != self.tokens:
-                raise ProtocolError("player %d uses a different character record (not supported yet)" % i)
+            self.records[i] = list(tok)
         return self
 
     def workload(self, rows, cols, map_bytes, portal=None, floors=1, H=64, Z=64, B=256, P=32, chests=9000, device=0):
         """The one-arena Battle workload of this match as seen by this client (`ind` = the server-assigned index)."""
         cfg = config.make_config(1, rows, cols, floors=floors, H=H, Z=Z, B=B, P=P, chests=chests,
                                  mode=abi.MODE_BATTLE, level=1, n_agents=self.n, teams=self.teams, auto_reset=0,
-                                 player_tokens=self.tokens, device=device, ind=self.ind)
+                                 player_tokens=self.tokens, device=device, ind=self.ind,
+                                 agent_tokens=self.records)  # every player is built from the record it sent
         return config.Workload("match", cfg, map_bytes, portal or [-1] * (floors * rows * cols))
 
     # -- per iteration ------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ namespace sf {
 // same variant choice as the HIP launchers: big flag planes stay in "HBM" (here: the host arrays)
 template <int NB>
 static void run_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
-  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad));
+  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab));
   for (int a = 0; a < p.A; ++a) {
     if (hbm_plane(p.cells_pad))
       Core<WaveEmu, NB, true>::reset_body(lds.data(), p, a, tb, serial);
@@ -28,7 +28,7 @@ static void run_reset(const Params &p, const uint64_t *tb, const uint64_t *seria
 }
 template <int NB>
 static void run_step(const Params &p, const uint8_t *cmds, int k) {
-  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad));
+  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab));
   for (int a = 0; a < p.A; ++a) {
     if (hbm_plane(p.cells_pad))
       Core<WaveEmu, NB, true>::step_body(lds.data(), p, a, cmds, k);

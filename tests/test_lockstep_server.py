@@ -58,7 +58,7 @@ def _world(d):
             d.flags.tobytes(), d.hdr.frame, d.hdr.jomle, tuple(d.hdr.rng))
 
 
-def run_match(make_sim, teams, quit_at=None, ticks=400):
+def run_match(make_sim, teams, quit_at=None, ticks=400, records=None):
     port, password = _free_port(), "sesame"
     proc = _start_server(port, password, teams)
     m, portal = config.synthetic_map(28, 36, wall_p=0.04, portal_pairs=1)
@@ -69,7 +69,8 @@ def run_match(make_sim, teams, quit_at=None, ticks=400):
 
     def client_thread(k):
         try:
-            c = lockstep.MatchClient("127.0.0.1", port, password, config.HUMAN_ENEMY_TOKENS, name="p%d" % k).connect()
+            rec = records[k] if records else config.HUMAN_ENEMY_TOKENS
+            c = lockstep.MatchClient("127.0.0.1", port, password, rec, name="p%d" % k).connect()
             sim = make_sim(c.workload(28, 36, m, portal, H=12, Z=10, B=48, P=8))
             rng = np.random.RandomState(1000 + c.ind)
 
@@ -126,6 +127,34 @@ def test_three_clients_through_the_reference_server():
     _check(results, worlds, out, teams)
     assert [r[5] for r in sorted(results)][1] == "quit"
     assert "quited" in out  # the server's own log line for the '_' it relayed (server.cpp:88-89)
+
+
+# three different account records, exchanged through the reference server as Human::log_file blobs (gameplay.hpp:120-151)
+RECORDS = [config.HUMAN_ENEMY_TOKENS,
+           [15000, 1000, 15000, 10, 10, 10, 300000, 60, 0, 0, 0, 1, 1, 1, 34] + [1] * 16 + [56],
+           config.HUMAN_TOKENS]
+
+
+def _check_records(worlds):
+    first = worlds[0][0][0]  # humans of iteration 0 as player 0 sees them: (alive, f, r, c, way, team, hp, stamina, ...)
+    assert [h[6] for h in first[:3]] == [1000, 15000, 1000]          # Hp of the three records
+    assert [h[7] for h in first[:3]] == [1000000, 15000, 1000]       # stamina
+
+
+def test_three_clients_with_different_account_records():
+    teams = [1, 2, 3]
+    results, worlds, out = run_match(Oracle, teams, ticks=150, records=RECORDS)
+    _check(results, worlds, out, teams)
+    _check_records(worlds)
+
+
+@pytest.mark.gpu
+def test_three_gpu_clients_with_different_account_records():
+    from strikeforce_amd import env
+    teams = [1, 2, 3]
+    results, worlds, out = run_match(env.ArenaBatch, teams, ticks=150, records=RECORDS)
+    _check(results, worlds, out, teams)
+    _check_records(worlds)
 
 
 @pytest.mark.gpu
