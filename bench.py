@@ -205,13 +205,33 @@ def main():
     gather = world > 1 or os.environ.get("SF_BENCH_FORCE_GATHER") == "1"
     n_rec = args.arenas * cfg.n_agents * 8
     rccl = gather and backend == "nccl"
+    torch_gather = False
     if rccl:
-        # the communicator is the library's own (sf_comm_init); torch.distributed only carries rank 0's unique id
-        uid = [env.ArenaBatch.comm_unique_id() if rank == 0 else None]
+        # the communicator is the library's own (sf_comm_init); torch.distributed only carries rank 0's unique id.
+        # Should the library's RCCL refuse to come up on this node, every rank falls back together to the same
+        # all-gather through torch.distributed (same RCCL collective, issued by torch) and the line says so.
+        res_all = [torch.zeros(world * n_rec, dtype=torch.int32, device="cuda") for _ in range(2)]
+        ok = 1
+        try:
+            uid = [env.ArenaBatch.comm_unique_id() if rank == 0 else None]
+        except env.StrikeForceError:
+            uid, ok = [None], 0
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
-        g.comm_init(uid[0], rank, world)
-        res_all = [torch.zeros(world * n_rec, dtype=torch.int32, device="cuda") for _ in range(2)]
+            ok = 1 if uid[0] is not None else 0
+        if ok:
+            try:
+                g.comm_init(uid[0], rank, world)
+            except env.StrikeForceError:
+                ok = 0
+        if world > 1:
+            t_ok = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            ok = int(t_ok.item())
+        if not ok:
+            rccl, torch_gather = False, world > 1
+            res_local = [torch.zeros(n_rec, dtype=torch.int32, device="cuda") for _ in range(2)]
+            pending = [None, None]
     launches = [0]
 
     def run(first, count):
@@ -222,6 +242,13 @@ def main():
             if rccl:  # sf_results_allgather: snapshot on the launch stream, ncclAllGather on the library's side stream
                 g.results_allgather(res_all[launches[0] & 1].data_ptr())
                 launches[0] += 1
+            elif torch_gather:
+                j = launches[0] & 1
+                launches[0] += 1
+                if pending[j] is not None:
+                    pending[j].wait()
+                g.results_device(res_local[j].data_ptr())
+                pending[j] = dist.all_gather_into_tensor(res_all[j], res_local[j], async_op=True)
             elif gather:  # rehearsal backend (gloo, ranks sharing one card): through host memory
                 res = torch.zeros(n_rec, dtype=torch.int32, device="cuda")
                 g.results_device(res.data_ptr())
@@ -232,6 +259,11 @@ def main():
     def drain():
         if rccl:
             g.comm_wait(host_too=True)
+        elif torch_gather:
+            for j in range(2):
+                if pending[j] is not None:
+                    pending[j].wait()
+                    pending[j] = None
 
     run(0, pre)  # untimed pre-roll: full-length launches, populations and clocks at steady state
     run(pre, args.warmup)
@@ -354,8 +386,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": describe_workload(args.workload, args.arenas, cfg),
                        "arenas_per_gpu": args.arenas, "steps_per_launch": steps_per_launch, "preroll_steps": pre,
-                       "parallelism": "arena-sharded x%d, no data-path collective; result records all-gathered over "
-                                      "RCCL (sf_results_allgather) after each launch" % world if world > 1 else
+                       "parallelism": ("arena-sharded x%d, no data-path collective; result records all-gathered over "
+                                       "RCCL (%s) after each launch"
+                                       % (world, "sf_results_allgather" if rccl else "torch.distributed fallback"
+                                          if torch_gather else "host rehearsal path")) if world > 1 else
                                       "one GPU, arena-sharded by construction (no data-path collective)"},
             # contract figure: ALGORITHMIC bytes per launch / measured launch time against HBM peak.  `traffic` is the
             # HBM bytes the counters saw for a launch of this length (None when that shape was not profiled): the arena
