@@ -124,7 +124,7 @@ SF_HD inline void obs_cell_emit(const ObsView &v, uint32_t fl, int32_t cdmg, uin
 
 // flag byte of the plain static cell of class c (0 '#', 1 '^', 2 'v', 3 'O', 4..7 chest of type c - 4)
 SF_HD inline uint32_t obs_class_flags(int c) {
-  return c == 0 ? SF_CELL_WALL : c == 1 ? SF_CELL_PIN_UP : c == 2 ? SF_CELL_PIN_DN : c == 3 ? SF_CELL_POUT
+  return c == 0 ? (uint32_t)SF_CELL_WALL : c == 1 ? (uint32_t)SF_CELL_PIN_UP : c == 2 ? (uint32_t)SF_CELL_PIN_DN : c == 3 ? (uint32_t)SF_CELL_POUT
        : (uint32_t)SF_CELL_CHEST | ((uint32_t)(c - 4) << SF_CELL_CONS_SHIFT);
 }
 
