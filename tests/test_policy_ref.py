@@ -146,3 +146,41 @@ def test_load_checkpoint_reads_a_torchscript_module_archive_and_a_state_dict(tmp
     torch.save(bad, str(tmp_path / "bad.pt"))
     with pytest.raises(ValueError):
         policy.load_checkpoint(str(tmp_path / "bad.pt"))
+
+
+def test_load_checkpoint_reads_what_libtorch_torch_save_writes(tmp_path):
+    """The real C++ writer: tests/tools/make_torch_archive.cpp registers AgentModel's parameter names on a module tree
+    and calls libtorch's `torch::save(module, path)` (Agent.hpp:124,159-161); policy.load_checkpoint must return every
+    tensor bit-for-bit.  Needs the libtorch headers and libraries that ship inside the torch wheel."""
+    import subprocess
+    import torch
+    from strikeforce_amd import policy
+    tdir = os.path.dirname(torch.__file__)
+    inc = [os.path.join(tdir, "include"), os.path.join(tdir, "include", "torch", "csrc", "api", "include")]
+    if not os.path.exists(os.path.join(inc[1], "torch", "torch.h")):
+        pytest.skip("no libtorch C++ headers in this torch build")
+    src = os.path.join(ROOT, "tests", "tools", "make_torch_archive.cpp")
+    bdir = os.path.join(ROOT, "tests", "tools", "_build")
+    os.makedirs(bdir, exist_ok=True)
+    exe = os.path.join(bdir, "make_torch_archive")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        cmd = ["g++", "-std=c++17", "-O1", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch.compiled_with_cxx11_abi()), src,
+               "-I" + inc[0], "-I" + inc[1], "-L" + os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10",
+               "-Wl,-rpath," + os.path.join(tdir, "lib"), "-o", exe]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            pytest.skip("libtorch test tool does not build here: " + r.stderr[-400:])
+    shapes = policy.parameter_shapes()
+    names = list(shapes)
+    spec = "".join("%s %s\n" % (n, " ".join(str(d) for d in shapes[n])) for n in names)
+    path = str(tmp_path / "model.pt")
+    r = subprocess.run([exe, path], input=spec, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    got = policy.load_checkpoint(path)
+    assert set(got) == set(names)
+    for k, n in enumerate(names):
+        size = int(np.prod(shapes[n]))
+        i = np.arange(size, dtype=np.uint64)
+        u = ((i * np.uint64(2654435761) + np.uint64(k * 40503)) & np.uint64(0xFFFFFFFF)) >> np.uint64(16)
+        want = (u.astype(np.float64) / 65536.0 - 0.5).astype(np.float32).reshape(shapes[n])
+        assert np.array_equal(got[n], want), n
