@@ -29,17 +29,19 @@ namespace sf {
 __device__ uint32_t sf_diag_buffer[16 * 65536];  // diagnostic build only: [arena][phase] wave cycles of the last launch
 #endif
 
-// HP (HBM_PLANE): maps whose flag plane is too large for LDS keep it in HBM (sf_core.hpp); dynamic LDS = power table only
-template <int NB, bool HP>
+// HP (HBM_PLANE): maps whose flag plane is too large for LDS keep it in HBM (sf_core.hpp).  BM (BITMAPS): the cell
+// bitmaps fit in LDS (every LDS-plane map, and HBM-plane maps up to 128 x 128).  Variants built: (HP 0, BM 1),
+// (HP 1, BM 1), (HP 1, BM 0).
+template <int NB, bool HP, bool BM>
 __global__ __launch_bounds__(64) void k_reset(Params p, const uint64_t *tb, const uint64_t *serial) {
   extern __shared__ __attribute__((aligned(2048))) uint8_t lds[];  // the RNG power table comes first (W::pow_pair)
-  Core<WaveGfx950, NB, HP>::reset_body(lds, p, (int)blockIdx.x, tb, serial);
+  Core<WaveGfx950, NB, HP, BM>::reset_body(lds, p, (int)blockIdx.x, tb, serial);
 }
 
-template <int NB, bool HP>
+template <int NB, bool HP, bool BM>
 __global__ __launch_bounds__(64) void k_step(Params p, const uint8_t *cmds, int k) {
   extern __shared__ __attribute__((aligned(2048))) uint8_t lds[];  // the RNG power table comes first (W::pow_pair)
-  Core<WaveGfx950, NB, HP>::step_body(lds, p, (int)blockIdx.x, cmds, k);
+  Core<WaveGfx950, NB, HP, BM>::step_body(lds, p, (int)blockIdx.x, cmds, k);
 }
 
 // check_end()'s verdict per (arena, agent) on the device (sf_done_device)
@@ -366,12 +368,15 @@ struct HipRT {
 
   template <int NB>
   int do_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
-    if (hbm_plane(p.cells_pad)) {
-      hipLaunchKernelGGL((k_reset<NB, true>), dim3((unsigned)p.A), dim3(64), (size_t)p.lds_tab, stream, p, tb, serial);
-    } else {
-      int rc = lds_attr(k_reset<NB, false>, lds_bytes_for(p.cells_pad, p.lds_tab));
+    const size_t lds = lds_bytes_for(p.cells_pad, p.lds_tab);
+    if (!hbm_plane(p.cells_pad)) {
+      int rc = lds_attr(k_reset<NB, false, true>, lds);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_reset<NB, false>), dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad, p.lds_tab), stream, p, tb, serial);
+      hipLaunchKernelGGL((k_reset<NB, false, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, tb, serial);
+    } else if (use_bitmaps(p.cells_pad)) {
+      hipLaunchKernelGGL((k_reset<NB, true, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, tb, serial);
+    } else {
+      hipLaunchKernelGGL((k_reset<NB, true, false>), dim3((unsigned)p.A), dim3(64), lds, stream, p, tb, serial);
     }
     SF_HIP(hipGetLastError());
     return SF_OK;
@@ -388,9 +393,10 @@ struct HipRT {
 
   template <int NB>
   int do_step(const Params &p, const uint8_t *cmds, int k) {
-    const bool hp = hbm_plane(p.cells_pad);
+    const bool hp = hbm_plane(p.cells_pad), bm = use_bitmaps(p.cells_pad);
+    const size_t lds = lds_bytes_for(p.cells_pad, p.lds_tab);
     if (!hp) {
-      int rc = lds_attr(k_step<NB, false>, lds_bytes_for(p.cells_pad, p.lds_tab));
+      int rc = lds_attr(k_step<NB, false, true>, lds);
       if (rc) return rc;
     }
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
@@ -404,10 +410,12 @@ struct HipRT {
       ev = &events[used_events++];
       SF_HIP(hipEventRecord(ev->first, stream));
     }
-    if (hp)
-      hipLaunchKernelGGL((k_step<NB, true>), dim3((unsigned)p.A), dim3(64), (size_t)p.lds_tab, stream, p, cmds, k);
+    if (!hp)
+      hipLaunchKernelGGL((k_step<NB, false, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, k);
+    else if (bm)
+      hipLaunchKernelGGL((k_step<NB, true, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, k);
     else
-      hipLaunchKernelGGL((k_step<NB, false>), dim3((unsigned)p.A), dim3(64), lds_bytes_for(p.cells_pad, p.lds_tab), stream, p, cmds, k);
+      hipLaunchKernelGGL((k_step<NB, true, false>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, k);
     SF_HIP(hipGetLastError());
     if (ev) SF_HIP(hipEventRecord(ev->second, stream));
     return SF_OK;

@@ -27,7 +27,8 @@ enum { LIM_PORTAL = 1000, LIM_BLOCK = 1100 };  // G:37
 // HBM_PLANE: the arena's flag plane is too large to stage in LDS next to enough other wavefronts (128x128 and up):
 // `lds` then points at the plane in HBM itself (L2-cached; the same accessors compile to global loads/stores) and
 // only the 2 KiB power table sits in LDS.
-template <class W, int NB, bool HBM_PLANE = false>
+// BITMAPS: the per-cell scratch bitmaps ("cell bitmaps" below) fit in LDS; without them the ballot loops run.
+template <class W, int NB, bool HBM_PLANE = false, bool BITMAPS = !HBM_PLANE>
 struct Core {
   using V = typename W::V;
   using P = typename W::P;
@@ -53,7 +54,7 @@ struct Core {
     const uint32_t *xt;
     // human_action's command-class / stat table in LDS (Tables::hatab, sf_types.hpp HT_*)
     const uint32_t *ht;
-    // BM_COUNT scratch bitmaps in LDS, one bit per cell, all-zero between uses ("cell bitmaps" below); null with HBM_PLANE
+    // BM_COUNT scratch bitmaps in LDS, one bit per cell, all-zero between uses ("cell bitmaps" below); null without BITMAPS
     uint32_t *bm;
     // one-deep lookahead of draw(): the log looked up for the next draw, and whether it is valid
     V la;  // valid whenever draw() can run: (re)issued by load(), srand_(), the adoption of a warmed-up generator, draw()
@@ -424,7 +425,7 @@ struct Core {
     const V ci0 = ((zq >> 20) * (uint32_t)p.N + zr) * (uint32_t)p.M + zc;  // the zombie's own cell index
     const V qn0 = zq + 1024u, qn1 = zq + 1u, qn2 = zq - 1024u, qn3 = zq - 1u;  // DX/DY order: down, right, up, left
     uint64_t skip = 0ull;
-    const bool use_bm = !HBM_PLANE;
+    const bool use_bm = BITMAPS;
     if (use_bm) {
       // humans and designated bullets scatter their cells into bitmaps; every zombie tests its own cell (a bullet
       // there: skip) and its four neighbours (a bullet: not '.'; a human: punch)
@@ -522,7 +523,7 @@ struct Core {
   static SF_DEV void portal_damage(Arena &S, uint8_t *lds, const Params &p) {
     SF_PROF(PH_PORTAL);
     uint64_t pm = W::ballot((S.ppos & PF_ACTIVE) != 0u) & capmask(p.P);
-    if (!HBM_PLANE) {
+    if (BITMAPS) {
       if (!pm) return;
       // an exit radiates unless it shows 'O': 'O' flag, no wall / entrance / chest flag, nobody and no designated
       // bullet on it (showit order G:321-346).  All exits at once: flags by gather, occupancy by cell bitmaps
@@ -656,8 +657,8 @@ struct Core {
   // ballots.  With the flag plane in LDS there is room for scratch bitmaps of one bit per cell next to it: one kind of
   // entity scatters its cells into a bitmap (LDS atomic OR, one instruction for all lanes), the other kind tests its
   // own cells (one gather), the bits are cleared again.  The bitmaps are all-zero outside such a build / test / clear
-  // bracket.  Big maps (HBM_PLANE) keep the ballot loops.
-  enum { BM_HUM = 0, BM_ZOM = 1, BM_REF = 2, BM_TMP = 3 };
+  // bracket.  Maps whose bitmaps would not fit (256 x 256) keep the ballot loops (BITMAPS false).
+  enum { BM_HUM = 0, BM_ZOM = 1, BM_REF = 2 };
   static SF_DEV V cell_index_v(const Params &p, const V &q) {  // packed position (flag bits above it ignored) -> cell
     return W::mad24(W::mad24((q >> 20) & 3u, (uint32_t)p.N, (q >> 10) & 1023u), (uint32_t)p.M, q & 1023u);
   }
@@ -754,7 +755,7 @@ struct Core {
       S.hfl = W::select(dying, W::select(W::lane() == (uint32_t)p.ind, S.hfl & ~HF_ALIVE, S.hfl & ~(HF_ALIVE | HF_CTRL | HF_OCC)), S.hfl);
     }
     const uint32_t my_team = (uint32_t)h_team(W::readlane(S.hfl, (uint32_t)p.ind));
-    if (!HBM_PLANE) {
+    if (BITMAPS) {
       // who stands on a designated bullet: the bullets scatter their cells, the characters test their own
       bool any = false;
 #pragma unroll
@@ -840,14 +841,14 @@ struct Core {
       S.ba[j] = W::select(pass, na, V(0u));
       S.bc[j] = W::select(pass, S.bc[j] + 0x10000u, S.bc[j]);
     }
-    if (!HBM_PLANE) {
+    if (BITMAPS) {
       // every surviving bullet has just entered its cell.  If no two of them entered the same cell (they claim their
       // cells in a scratch bitmap), each one is its cell's last entrant and is designated, whatever the sweep order
       uint64_t dup = 0ull;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) dup |= W::ballot(bm_claim(S, p, BM_TMP, nci[j], passed[j]));
+      for (int j = 0; j < NB; ++j) dup |= W::ballot(bm_claim(S, p, BM_HUM, nci[j], passed[j]));
 #pragma unroll
-      for (int j = 0; j < NB; ++j) bm_clear(S, p, BM_TMP, nci[j], passed[j]);
+      for (int j = 0; j < NB; ++j) bm_clear(S, p, BM_HUM, nci[j], passed[j]);
       if (!dup) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) S.ba[j] = W::select(passed[j], S.ba[j] | BA_REF, S.ba[j]);
@@ -1155,7 +1156,7 @@ struct Core {
     const P needb = inb & (((tfl & SF_CELL_POUT) != 0u) | is_place);
     P oH, oZ, oB;
     bool slow = W::ballot(live & ((ofl & (SF_CELL_PIN_UP | SF_CELL_PIN_DN | SF_CELL_CHEST)) != 0u)) != 0ull;
-    if (!HBM_PLANE) {
+    if (BITMAPS) {
       // occupants scatter their cells into bitmaps, the acting humans test their target cells.  A fourth bitmap
       // holds the cells of humans that may walk away in this sweep, then the claims of the targets themselves
       const P hocc = (S.hfl & HF_OCC) != 0u, zlive = (S.zpos & ZF_ALIVE) != 0u;
@@ -1164,16 +1165,17 @@ struct Core {
       bm_set(S, p, BM_HUM, hci, hocc);
       bm_set(S, p, BM_ZOM, zci, zlive);
       if (bul) bm_bullets(S, p, BM_REF, true);
-      bm_set(S, p, BM_TMP, oci, is_move);
       oH = bm_test(S, p, BM_HUM, tci, inb), oZ = bm_test(S, p, BM_ZOM, tci, inb);
       oB = needb & bm_test(S, p, BM_REF, tci, needb);
-      const P leaves = inb & bm_test(S, p, BM_TMP, tci, inb);
       bm_clear(S, p, BM_HUM, hci, hocc);
       bm_clear(S, p, BM_ZOM, zci, zlive);
       if (bul) bm_bullets(S, p, BM_REF, false);
-      bm_clear(S, p, BM_TMP, oci, is_move);
-      const P shared = bm_claim(S, p, BM_TMP, tci, inb);
-      bm_clear(S, p, BM_TMP, tci, inb);
+      // (the bitmaps are free again) the cells of humans that may walk away, then the claims of the targets
+      bm_set(S, p, BM_HUM, oci, is_move);
+      const P shared = bm_claim(S, p, BM_ZOM, tci, inb);
+      const P leaves = inb & bm_test(S, p, BM_HUM, tci, inb);
+      bm_clear(S, p, BM_HUM, oci, is_move);
+      bm_clear(S, p, BM_ZOM, tci, inb);
       if (W::ballot(leaves | shared)) slow = true;
     } else {
       const uint64_t movers = W::ballot(is_move);
@@ -1610,8 +1612,8 @@ struct Core {
     S.xt = reinterpret_cast<const uint32_t *>(tab);
     S.ht = reinterpret_cast<const uint32_t *>(tab + LDS_EXP_BYTES);
     S.bm = nullptr;
-    if (!HBM_PLANE) {
-      S.bm = reinterpret_cast<uint32_t *>(lds + p.lds_tab + p.cells_pad);
+    if (BITMAPS) {
+      S.bm = reinterpret_cast<uint32_t *>(lds + p.lds_tab + (HBM_PLANE ? 0 : p.cells_pad));
       W::lds_zero(S.bm, (uint32_t)(BM_COUNT * p.bm_words));
     }
     S.la = V(0u);

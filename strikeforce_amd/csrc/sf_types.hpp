@@ -4,6 +4,7 @@
 // owns arena `a` loads field f of all its entities with one coalesced instruction
 // (address = base_f + (a * CAP + lane) * 4).  See DESIGN.md §Layout.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 // SF_HD: usable from host code and from gfx950 device code (hipcc defines the qualifiers; the
@@ -134,14 +135,21 @@ constexpr int LOGT_OFF = 512;
 constexpr int LOGT_ENTRIES = LOGT_OFF + 65537;
 
 // Per-arena scratch bitmaps in LDS, one bit per cell (sf_core.hpp "cell bitmaps"): only with the flag plane in LDS
-constexpr int BM_COUNT = 4;
+constexpr int BM_COUNT = 3;
+inline int bm_words_for(int cells);
+// bitmaps are used when the three of them take at most 6 KiB of LDS per arena (maps up to 128 x 128 cells): with the
+// flag plane in LDS (<= 12 KiB) that always holds, with the plane in HBM it admits 128 x 128 but not 256 x 256
+inline bool use_bitmaps(int cells_pad) { return BM_COUNT * 4 * bm_words_for(cells_pad) <= 6 * 1024; }
 inline int bm_words_for(int cells) { return ((cells + 31) / 32 + 3) & ~3; }  // words per bitmap, 16-byte multiple
 
 inline int nb_for(int B) { return (B + 63) / 64; }
 constexpr int LDS_EXP_BYTES = 2048;                                   // exptab, then Tables::hatab (Params::lds_tab)
 inline int lds_tab_for(int blocks) { return LDS_EXP_BYTES + ht_bytes_for(blocks); }
+inline bool hbm_plane(int cells_pad);
+// LDS of a workgroup: [exptab][hatab][flag plane unless it stays in HBM][bitmaps if used]
 inline size_t lds_bytes_for(int cells_pad, int lds_tab) {
-  return (size_t)cells_pad + (size_t)lds_tab + (size_t)BM_COUNT * 4u * (size_t)bm_words_for(cells_pad);
+  return (size_t)lds_tab + (hbm_plane(cells_pad) ? 0u : (size_t)cells_pad) +
+         (use_bitmaps(cells_pad) ? (size_t)BM_COUNT * 4u * (size_t)bm_words_for(cells_pad) : 0u);
 }
 // flag planes above this size stay in HBM (Core<.., HBM_PLANE>): staging them would leave < 12 wavefronts per CU
 constexpr int LDS_PLANE_MAX = 12 * 1024;

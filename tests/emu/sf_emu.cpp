@@ -20,20 +20,24 @@ template <int NB>
 static void run_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
   std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab));
   for (int a = 0; a < p.A; ++a) {
-    if (hbm_plane(p.cells_pad))
-      Core<WaveEmu, NB, true>::reset_body(lds.data(), p, a, tb, serial);
+    if (!hbm_plane(p.cells_pad))
+      Core<WaveEmu, NB, false, true>::reset_body(lds.data(), p, a, tb, serial);
+    else if (use_bitmaps(p.cells_pad))
+      Core<WaveEmu, NB, true, true>::reset_body(lds.data(), p, a, tb, serial);
     else
-      Core<WaveEmu, NB, false>::reset_body(lds.data(), p, a, tb, serial);
+      Core<WaveEmu, NB, true, false>::reset_body(lds.data(), p, a, tb, serial);
   }
 }
 template <int NB>
 static void run_step(const Params &p, const uint8_t *cmds, int k) {
   std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab));
   for (int a = 0; a < p.A; ++a) {
-    if (hbm_plane(p.cells_pad))
-      Core<WaveEmu, NB, true>::step_body(lds.data(), p, a, cmds, k);
+    if (!hbm_plane(p.cells_pad))
+      Core<WaveEmu, NB, false, true>::step_body(lds.data(), p, a, cmds, k);
+    else if (use_bitmaps(p.cells_pad))
+      Core<WaveEmu, NB, true, true>::step_body(lds.data(), p, a, cmds, k);
     else
-      Core<WaveEmu, NB, false>::step_body(lds.data(), p, a, cmds, k);
+      Core<WaveEmu, NB, true, false>::step_body(lds.data(), p, a, cmds, k);
   }
 }
 
