@@ -425,6 +425,15 @@ struct Core {
     const V ci0 = ((zq >> 20) * (uint32_t)p.N + zr) * (uint32_t)p.M + zc;  // the zombie's own cell index
     const V qn0 = zq + 1024u, qn1 = zq + 1u, qn2 = zq - 1024u, qn3 = zq - 1u;  // DX/DY order: down, right, up, left
     uint64_t skip = 0ull;
+    // the four neighbours' flag bytes first, all four loads in flight at once (with the plane in HBM each is an L2 round
+    // trip): a neighbour off the map reads the zombie's own cell instead and is masked afterwards
+    V nfl[4];
+    P ninb[4];
+    for (int d = 0; d < 4; ++d) {
+      const V rr = zr + (uint32_t)DX(d), cc = zc + (uint32_t)DY(d);
+      ninb[d] = zalive & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
+      nfl[d] = W::lds_u8_any(lds, W::select(ninb[d], ci0 + (uint32_t)(DX(d) * p.M + DY(d)), W::select(zalive, ci0, V(0u))));
+    }
     const bool use_bm = BITMAPS;
     if (use_bm) {
       // humans and designated bullets scatter their cells into bitmaps; every zombie tests its own cell (a bullet
@@ -435,10 +444,9 @@ struct Core {
       bm_bullets(S, p, BM_REF, true);
       skip = W::ballot(zalive & bm_test(S, p, BM_REF, ci0, zalive));
       for (int d = 0; d < 4; ++d) {
-        const V rr = zr + (uint32_t)DX(d), cc = zc + (uint32_t)DY(d);
-        const P inb = zalive & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
+        const P inb = ninb[d];
         const V ci = ci0 + (uint32_t)(DX(d) * p.M + DY(d));
-        const V fl = W::lds_u8(lds, ci, inb);
+        const V fl = nfl[d];
         const P clear = inb & (fl == 0u) & (!bm_test(S, p, BM_REF, ci, inb));
         freebits = freebits | W::select(clear, V(1u << d), V(0u));
         hnear = hnear | W::select(inb & bm_test(S, p, BM_HUM, ci, inb), V(1u << d), V(0u));
@@ -446,13 +454,7 @@ struct Core {
       bm_clear(S, p, BM_HUM, hci, hocc);
       bm_bullets(S, p, BM_REF, false);
     } else {
-      for (int d = 0; d < 4; ++d) {
-        const V rr = zr + (uint32_t)DX(d), cc = zc + (uint32_t)DY(d);
-        const P inb = zalive & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
-        const V ci = ci0 + (uint32_t)(DX(d) * p.M + DY(d));
-        const V fl = W::lds_u8(lds, ci, inb);
-        freebits = freebits | W::select(inb & (fl == 0u), V(1u << d), V(0u));
-      }
+      for (int d = 0; d < 4; ++d) freebits = freebits | W::select(ninb[d] & (nfl[d] == 0u), V(1u << d), V(0u));
       // designated bullets present at phase start: own cell -> skip; neighbour cell -> not '.'
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
@@ -522,53 +524,45 @@ struct Core {
   // portal_damage G:1279-1297
   static SF_DEV void portal_damage(Arena &S, uint8_t *lds, const Params &p) {
     SF_PROF(PH_PORTAL);
-    uint64_t pm = W::ballot((S.ppos & PF_ACTIVE) != 0u) & capmask(p.P);
-    if (BITMAPS) {
-      if (!pm) return;
-      // an exit radiates unless it shows 'O': 'O' flag, no wall / entrance / chest flag, nobody and no designated
-      // bullet on it (showit order G:321-346).  All exits at once: flags by gather, occupancy by cell bitmaps
-      const P act = ((S.ppos & PF_ACTIVE) != 0u) & W::ltu(W::lane(), (uint32_t)p.P);
-      const V pci = cell_index_v(p, S.ppos);
-      const V fl = W::lds_u8(lds, pci, act);
-      const P plain = act & ((fl & (uint32_t)(SF_CELL_WALL | SF_CELL_PIN_UP | SF_CELL_PIN_DN | SF_CELL_CHEST | SF_CELL_POUT)) ==
-                             (uint32_t)SF_CELL_POUT);
-      uint64_t need = pm;
-      const uint64_t plm = W::ballot(plain);
-      if (plm && !(plm & (plm - 1ull))) {  // a single exit: three ballots beat three bitmaps
+    const uint64_t pm = W::ballot((S.ppos & PF_ACTIVE) != 0u) & capmask(p.P);
+    if (!pm) return;
+    // an exit radiates unless it shows 'O': 'O' flag, no wall / entrance / chest flag, nobody and no designated
+    // bullet on it (showit order G:321-346).  All exits at once: their flag bytes by one gather (one L2 round trip
+    // for a plane kept in HBM, instead of one per exit), occupancy by the cell bitmaps or, for a single exit and on
+    // maps without bitmaps, by three ballots per exit
+    const P act = ((S.ppos & PF_ACTIVE) != 0u) & W::ltu(W::lane(), (uint32_t)p.P);
+    const V pci = cell_index_v(p, S.ppos);
+    const V fl = W::lds_u8(lds, pci, act);
+    const P plain = act & ((fl & (uint32_t)(SF_CELL_WALL | SF_CELL_PIN_UP | SF_CELL_PIN_DN | SF_CELL_CHEST | SF_CELL_POUT)) ==
+                           (uint32_t)SF_CELL_POUT);
+    uint64_t need = pm;
+    uint64_t plm = W::ballot(plain);
+    if (BITMAPS && (plm & (plm - 1ull))) {
+      const P hocc = (S.hfl & HF_OCC) != 0u, zlive = (S.zpos & ZF_ALIVE) != 0u;
+      const V hci = cell_index_v(p, S.hpos), zci = cell_index_v(p, S.zpos);
+      bm_set(S, p, BM_HUM, hci, hocc);
+      bm_set(S, p, BM_ZOM, zci, zlive);
+      bm_bullets(S, p, BM_REF, true);
+      const P covered = bm_test(S, p, BM_HUM, pci, plain) | bm_test(S, p, BM_ZOM, pci, plain) | bm_test(S, p, BM_REF, pci, plain);
+      bm_clear(S, p, BM_HUM, hci, hocc);
+      bm_clear(S, p, BM_ZOM, zci, zlive);
+      bm_bullets(S, p, BM_REF, false);
+      need = pm & ~W::ballot(plain & (!covered));
+    } else {
+      while (plm) {
         const uint32_t i = (uint32_t)W::ctz64(plm);
+        const uint64_t bit = plm & (0ull - plm);
+        plm ^= bit;
         const uint32_t q = W::readlane(S.ppos, i) & POS_MASK;
-        if (human_at(S, q) < 0 && zombie_at(S, q) < 0 && refbullet_at(S, q) < 0) need &= ~plm;
-      } else if (plm) {
-        const P hocc = (S.hfl & HF_OCC) != 0u, zlive = (S.zpos & ZF_ALIVE) != 0u;
-        const V hci = cell_index_v(p, S.hpos), zci = cell_index_v(p, S.zpos);
-        bm_set(S, p, BM_HUM, hci, hocc);
-        bm_set(S, p, BM_ZOM, zci, zlive);
-        bm_bullets(S, p, BM_REF, true);
-        const P covered = bm_test(S, p, BM_HUM, pci, plain) | bm_test(S, p, BM_ZOM, pci, plain) | bm_test(S, p, BM_REF, pci, plain);
-        bm_clear(S, p, BM_HUM, hci, hocc);
-        bm_clear(S, p, BM_ZOM, zci, zlive);
-        bm_bullets(S, p, BM_REF, false);
-        need = pm & ~W::ballot(plain & (!covered));
+        if (human_at(S, q) < 0 && zombie_at(S, q) < 0 && refbullet_at(S, q) < 0) need &= ~bit;
       }
-      while (need) {
-        const uint32_t i = (uint32_t)W::ctz64(need);
-        need &= need - 1ull;
-        int index = b_ind(S, p);
-        if (index == -1) return;
-        bullet_put(S, index, W::readlane(S.ppos, i) & POS_MASK, 3, 20, -10, 1, 0);  // radiation.ready(20, -10, 1); shot(v, 3, radiation, 0)
-      }
-      return;
     }
-    while (pm) {
-      const uint32_t i = (uint32_t)W::ctz64(pm);
-      pm &= pm - 1ull;
-      const uint32_t q = W::readlane(S.ppos, i) & POS_MASK;
-      uint32_t fl;
-      if (showit_q(S, lds, p, q, fl) != SH_POUT) {
-        int index = b_ind(S, p);
-        if (index == -1) return;
-        bullet_put(S, index, q, 3, 20, -10, 1, 0);  // radiation.ready(20, -10, 1); shot(v, 3, radiation, 0)
-      }
+    while (need) {
+      const uint32_t i = (uint32_t)W::ctz64(need);
+      need &= need - 1ull;
+      int index = b_ind(S, p);
+      if (index == -1) return;
+      bullet_put(S, index, W::readlane(S.ppos, i) & POS_MASK, 3, 20, -10, 1, 0);  // radiation.ready(20, -10, 1); shot(v, 3, radiation, 0)
     }
   }
 

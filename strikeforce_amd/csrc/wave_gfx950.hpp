@@ -126,6 +126,7 @@ struct WaveGfx950 {
 
   // LDS flag plane
   static SF_DEV V lds_u8(const uint8_t *lds, V idx, P pred) { return pred ? (uint32_t)lds[idx] : 0u; }
+  static SF_DEV V lds_u8_any(const uint8_t *lds, V idx) { return (uint32_t)lds[idx]; }  // every lane: idx must be valid
   static SF_DEV uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return uni((uint32_t)lds[idx]); }
   static SF_DEV V lds_u32(const uint32_t *lds, V idx, P pred) { return pred ? lds[idx] : 0u; }
   // the same with a wave-uniform first factor, which stays in an SGPR (VOP2 src0)

@@ -251,6 +251,12 @@ struct WaveEmu {
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
     return r;
   }
+  static V lds_u8_any(const uint8_t *lds, const V &idx) {
+    EMU_OP();
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = lds[idx.v[i]];
+    return r;
+  }
   static uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) {
     EMU_SOP();
     return lds[idx];
