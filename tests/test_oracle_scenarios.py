@@ -194,3 +194,76 @@ def test_punch_only_profile_cannot_select_weapons(impl):
         h = x.humans[0]
         assert (h.vec, h.ind, h.stamina) == (-1, -1, 1000)
         assert sum(b.alive for b in x.bullets) == 0
+
+
+# ---- zombies: found by searching seeds on the oracle (the search only chose the seed; every expectation below is derived
+# by hand from the reference lines cited) --------------------------------------------------------------------------
+def small_open_workload(seed):
+    """8x8 map with an open 6x6 floor, one zombie slot, no NPC slot, no chests: the only entity besides the player is
+    the zombie that the first loop top spawns (G:1446-1447: frame 1 % 40 <= 1)."""
+    rows = cols = 8
+    grid = [["#"] * cols for _ in range(rows)]
+    for r in range(1, rows - 1):
+        for c in range(1, cols - 1):
+            grid[r][c] = "."
+    m = "".join("".join(x) for x in grid).encode()
+    cfg = config.make_config(1, rows, cols, H=1, Z=1, B=8, P=4, chests=0, auto_reset=0)
+    w = config.Workload("small", cfg, m, [-1] * (rows * cols))
+    w.seed = seed
+    return w
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_zombie_next_to_the_player_punches_every_step_and_draws_nothing(impl):
+    # seed 1700000041: the zombie walks onto (2,1), the cell in front of the player, within two steps.  From then on
+    # zombie_action finds a human on a neighbour cell: it punches (a range-1 bullet of damage max(0, mindamage) = 100,
+    # effect 0, on the human's cell, CH:838-844) and `continue`s before any rand() (G:664-677); hit_human applies it in
+    # the same half-tick: Hp -= 100, mindamage += 0 (CH:242-246, G:611-634).
+    _, s = run(small_open_workload(1700000041), "++" + "+++", impl)
+    z = s[2].zombies[0]
+    assert (z.alive, z.r, z.c, z.super_, z.hp, z.mindamage) == (1, 2, 1, 0, 400, 100)
+    assert s[2].humans[0].hp == 1000
+    for k in (3, 4, 5):
+        h, z = s[k].humans[0], s[k].zombies[0]
+        assert (h.hp, h.mindamage) == (1000 - 100 * (k - 2), 100)
+        assert (z.r, z.c, z.hp) == (2, 1, 400)
+        assert sum(b.alive for b in s[k].bullets) == 0  # the punch was consumed by the hit
+        # draws of such a step: update_bull twice (G:1073), human_action's sweep direction once (G:1002) = 3, plus
+        # three coordinates per spawn attempt whose frame is due (G:532-572; both attempts end at the full slot pools)
+        f = s[k - 1].hdr.frame  # the frame at the loop top that preceded this step was counted in the step before
+        spawn = 3 * ((s[k].hdr.frame % 40 <= 1) + (s[k].hdr.frame % 50 <= 1))
+        assert s[k].hdr.jomle - s[k - 1].hdr.jomle == 3 + spawn, (k, f)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_player_punches_the_zombie_dead_and_is_credited(impl):
+    # same seed; the player (facing down, G:1905-1920) punches the zombie on (2,1): max(compute_damage(100,1) = 10,
+    # mindamage 100) = 100 per punch (CH:391-397); zombie_damage credits the owner's damage and, on death, kills;
+    # owner == hum[ind] on the player's team: teams_kills + 1, loot += 500/10 + 500*9/10, kills + 1 (G:574-598).
+    # The zombie keeps punching until it dies: four exchanges.
+    _, s = run(small_open_workload(1700000041), "++" + "zzzz" + "+", impl)
+    for k in range(1, 5):
+        h, z = s[2 + k].humans[0], s[2 + k].zombies[0]
+        assert h.hp == 1000 - 100 * k and h.damage == 100 * k
+        assert (z.alive, z.hp) == ((1, 400 - 100 * k) if k < 4 else (0, z.hp))
+    d = s[6]
+    assert (d.hdr.kills, d.hdr.teams_kills, d.hdr.loot, d.humans[0].kills) == (1, 1, 500, 1)
+    assert s[7].humans[0].hp == 600 and s[7].hdr.done == 0  # nobody left to punch; Solo level 1 needs 5 kills (G:1147-1160)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_chest_pickup(impl):
+    # seed 1700000095: the first loop top (frame 1, G:1444-1445) drops a chest of type 2 (Items/cons2.txt: stamina 20,
+    # Hp 50, effect 10) on (1,2) and no zombie.  'd' moves the player onto it (showit '?' is enterable, G:750-756) and
+    # claim_chest (G:507-515, CH:372-377) adds stamina / Hp / effect-to-mindamage, clears s[4] and decrements `chest`.
+    w = small_open_workload(1700000095)
+    w.cfg.cap_chests = 5
+    _, s = run(w, "d" + "+", impl)
+    cell = 1 * 8 + 2
+    assert s[0].flags[cell] == abi.CELL_CHEST | (2 << abi.CELL_CONS_SHIFT) and s[0].hdr.chests == 1
+    assert sum(z.alive for z in s[0].zombies) == 0
+    h = s[1].humans[0]
+    assert (h.r, h.c) == (1, 2)
+    assert (h.stamina, h.hp, h.mindamage) == (1000000 + 20, 1000 + 50, 100 + 10)
+    assert s[1].flags[cell] == 0 and s[1].hdr.chests == 0
+    assert (s[2].humans[0].stamina, s[2].humans[0].hp) == (1000020, 1050)  # claimed once
