@@ -94,6 +94,13 @@ int sf_policy_kernel_time(sf_policy *p, int32_t enable, float *ms, double *flop,
 int sf_policy_gemm(sf_policy *p, const float *d_a, int32_t lda, const float *d_w, const float *d_bias, float *d_c,
                    int32_t ldc, int32_t m, int32_t n, int32_t k);
 
+/* The same product through the bf16-split kernel that conv1 and conv2 use once M >= 16 384 (k_gemm_b3: every f32
+ * operand as three bf16 parts, six v_mfma_f32_32x32x16_bf16 per block instead of eight f32 ones, f32-level error:
+ * |err| <= 2e-6 * sum|a*w|).  W is split on the device by this call (the network's own weights are split once at
+ * sf_policy_create); synchronous.  For unit tests and roofline measurements. */
+int sf_policy_gemm_split(sf_policy *p, const float *d_a, int32_t lda, const float *d_w, const float *d_bias, float *d_c,
+                         int32_t ldc, int32_t m, int32_t n, int32_t k);
+
 int sf_policy_abi_version(void);
 
 #ifdef __cplusplus

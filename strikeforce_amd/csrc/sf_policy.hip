@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/strikeforce_policy.h"
@@ -66,6 +67,7 @@ struct Gemm {
   // the two gate products of a GRU cell, or for the same layer of the two heads)
   const float *A2, *W2, *bias2;
   float *C2;
+  const void *W3;     // k_gemm_b3: W split into bf16 hi / mid / lo parts (split_weights)
 };
 
 constexpr int BN = 160;
@@ -335,6 +337,348 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(Gemm g, int KT, int G) {
       *reinterpret_cast<f32x4 *>(g.C + (size_t)(m0 + ml) * g.ldc + n0 + nl) = v;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gemm_b3: the large-M products (conv1, conv2) on the bf16 matrix pipe at f32-level accuracy.
+//
+// Every f32 operand is written as hi + mid + lo, three bf16 numbers obtained by round-to-nearest of the running
+// residual (x - hi and x - hi - mid are exact in f32, so hi + mid + lo == x: 3 x 8 significand bits and two signs cover
+// f32's 24).  A product a*w then expands into nine bf16 products; the six of relative size >= 2^-16 are kept
+//     hi*hi + (hi*mid + mid*hi) + (mid*mid + hi*lo + lo*hi)
+// and the dropped ones (mid*lo, lo*mid, lo*lo) are <= 3 * 2^-24 |a*w|: the order of one f32 rounding of the
+// product.  Each kept product is exact in the f32 accumulator (8 x 8 bits), so what differs from the f32 pipe is that
+// dropped tail and the summation order.  v_mfma_f32_32x32x16_bf16 retires 16 times the products per cycle of
+// v_mfma_f32_32x32x2_f32: six of them instead of eight f32 instructions per 32x32x16 block = 2.67 x fewer
+// matrix-pipe cycles.  Non-finite inputs come out as NaN (inf - inf in the residual).
+//
+// W is split once on the host into the image the LDS wants (one 96-byte record [hi 16][mid 16][lo 16] per (K tile of
+// 16, output column)); activations are split as they are stored to LDS (v_cvt_pk_bf16_f32 + shifts, ~5.5 VALU per
+// element, issued in the gaps of the other wave's MFMAs).  Block tile 256 rows x 160 columns x 16, eight waves of 32
+// rows x 160 columns (two per SIMD), one block per CU, two LDS stages of 39 KB (layout: see `adst` in the kernel).
+// Work split, pipeline and tile hand-over (stream-K runs, k_gemm_fixup) as in k_gemm.
+// ---------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef B3_EXP
+#define B3_EXP 0  // tools/r02_b3_exp.sh: ablations of k_gemm_b3 (wrong results, timing only)
+#endif
+#ifndef B3_WAVES
+#define B3_WAVES 8  // waves per block: 4 (128 rows, two blocks per CU) or 8 (256 rows, one block per CU)
+#endif
+constexpr int B3_BM = 32 * B3_WAVES, B3_BK = 16, B3_T = 64 * B3_WAVES, B3_RS = 96;
+constexpr int B3_BLOCKS_PER_CU = 8 / B3_WAVES;
+constexpr int B3_A_BYTES = B3_BM * B3_RS, B3_W_BYTES = BN * B3_RS, B3_STAGE = B3_A_BYTES + B3_W_BYTES;
+constexpr int B3_LDS = 2 * B3_STAGE;                 // 79 872 bytes
+constexpr int B3_W_PIECES = BN * 96 / 16;            // 16-byte pieces of one K tile of the W image: 960
+
+__device__ inline uint32_t pk_bf16(float a, float b) {
+  const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+  return __builtin_bit_cast(uint32_t, h);
+}
+// four f32 -> their hi / mid / lo bf16 parts, packed in k order
+__device__ inline void split3(const f32x4 x, u32x2 &hi, u32x2 &mid, u32x2 &lo) {
+  float r[4] = {x.x, x.y, x.z, x.w};
+  uint32_t o[3][2];
+#pragma unroll
+  for (int lvl = 0; lvl < 3; ++lvl)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t pk = pk_bf16(r[2 * h], r[2 * h + 1]);
+      o[lvl][h] = pk;
+      if (lvl < 2) {
+        // (asm: the compiler would pair these into v_pk_add_f32, which costs an MFMA-paced wave ~6x a plain one)
+        asm("v_sub_f32 %0, %0, %1" : "+v"(r[2 * h]) : "v"(pk << 16));
+        asm("v_sub_f32 %0, %0, %1" : "+v"(r[2 * h + 1]) : "v"(pk & 0xffff0000u));
+      }
+    }
+  hi = u32x2{o[0][0], o[0][1]}, mid = u32x2{o[1][0], o[1][1]}, lo = u32x2{o[2][0], o[2][1]};
+}
+
+// W [N][K] f32 -> k_gemm_b3's image [N / 160][K / 16][160][hi 16 | mid 16 | lo 16] (sf_policy_gemm_split; the
+// network's own weights are split on the host by split_weights, same arithmetic)
+__global__ void k_split_weights(const float *W, uint16_t *img, int N, int K) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)N * K) return;
+  const int n = (int)(e / K), k = (int)(e - (size_t)n * K);
+  float r = W[e];
+  uint16_t part[3];
+#pragma unroll
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    const uint32_t pk = pk_bf16(r, 0.f);
+    part[lvl] = (uint16_t)pk;
+    r -= __builtin_bit_cast(float, pk << 16);
+  }
+  const size_t rec = (((size_t)(n / BN) * (K / B3_BK) + k / B3_BK) * BN + n % BN) * 48 + k % B3_BK;
+  img[rec] = part[0], img[rec + 16] = part[1], img[rec + 32] = part[2];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(B3_T, B3_BLOCKS_PER_CU) void k_gemm_b3(Gemm g) {
+  constexpr int BM = B3_BM, NT = 5;
+  extern __shared__ __attribute__((aligned(16))) unsigned char b3_lds[];
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int n0 = blockIdx.y * BN;
+  const int KT = g.K / B3_BK;
+  const int u0 = run_start(g, blockIdx.x);
+  const int nu = g.unit_base + ((int)blockIdx.x < g.unit_rem ? 1 : 0);
+  if (nu == 0) return;
+
+  // this thread's two float4 of an A tile: rows (t >> 2) and (t >> 2) + 128, k offset 4 * (t & 3)
+  const float *arow[2];
+  auto setrow = [&](int tile) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int m = tile * BM + (t >> 2) + (BM / 2) * j;
+      if (m >= g.M) m = g.M - 1;
+      if (B3_EXP == 6) m &= 255;  // every tile reads the first one: A from L2
+      if (MODE == MODE_DENSE) {
+        arow[j] = g.A + (size_t)m * g.lda + (t & 3) * 4;
+      } else {
+        const int so2 = g.So * g.So;
+        const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
+        arow[j] = g.A + ((size_t)(b * g.S + 2 * oy) * g.S + 2 * ox) * g.Cin + (t & 3) * 4;
+      }
+    }
+  };
+  // its two 16-byte pieces of a W tile (the second one only for t < 448) and where they go in a stage
+  const u32x4 *wimg = reinterpret_cast<const u32x4 *>(g.W3) + (size_t)blockIdx.y * KT * B3_W_PIECES;
+  constexpr int NP = (B3_W_PIECES + B3_T - 1) / B3_T;  // pieces per thread (the last one only on some threads)
+  const bool wlast = t + (NP - 1) * B3_T < B3_W_PIECES;
+  // LDS image of a tile: row r = 96 bytes [hi 32][mid 32][lo 32], the two 16-byte k halves of each part swapped on rows
+  // with bit 3 set.  Conflict-free for every access: the sixteen rows of a ds_read_b128 lane group land on sixteen
+  // different 16-byte slots (6 r mod 16 alone would only reach the eight even ones), four rows of a ds_write_b64 group
+  // tile the 128-byte bank window (96 r mod 128 = 0, 96, 64, 32), and the W pieces stay contiguous.
+  auto wdst = [](int piece) { const int n = piece / 6, c = piece % 6; return B3_A_BYTES + n * B3_RS + ((c ^ ((n >> 3) & 1)) * 16); };
+  int wdstp[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) wdstp[q] = wdst(t + q * B3_T);
+  const int adst = (t >> 2) * B3_RS + ((((t & 3) >> 1) ^ ((t >> 5) & 1)) * 16) + (t & 1) * 8;
+
+  // two register sets: a unit is loaded three units before its MFMAs (two before it is split into LDS) — one unit is
+  // 1.5 us, less than an HBM round trip under load
+  f32x4 ra[2][2];
+  u32x4 rb[2][NP];
+  // one unit's global loads, one instruction per call (`which`: 0, 1 = the A float4, 2.. = the W pieces; -1 = all).
+  // Issued one at a time behind different MFMAs: the CU's address unit takes ~16 cycles per dwordx4 instruction, and
+  // eight waves issuing four each at the same point kept every wave ~900 cycles in that filler (in-order issue).
+  int gl_off = 0;
+  const u32x4 *gl_ws = wimg;
+  auto gload = [&](int kt, auto set, int which) {
+    constexpr int R = decltype(set)::value;
+    if (which <= 0) {
+      int off = kt * B3_BK;
+      if (MODE == MODE_NHWC) {
+        const int tap = off / g.Cin, c0 = off - tap * g.Cin, ky = tap / 3, kx = tap - ky * 3;
+        off = (ky * g.S + kx) * g.Cin + c0;
+      }
+      gl_off = off;
+      gl_ws = wimg + (size_t)kt * B3_W_PIECES;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (which < 0 || which == j) ra[R][j] = ldg4(arow[j] + gl_off);
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+      if (which < 0 || which == 2 + q) rb[R][q] = gl_ws[q + 1 < NP || wlast ? t + q * B3_T : t];
+  };
+  // `what`: 0, 1 = the two A float4 (split), 2 = the W pieces; spread over a unit's groups so that no burst of VALU and
+  // LDS stores starves the matrix pipe
+  auto lstore = [&](int stage, auto set, int what) {
+    constexpr int R = decltype(set)::value;
+    unsigned char *base = b3_lds + stage * B3_STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (what != j && what != 3) continue;
+      u32x2 hi, mid, lo;
+      if (B3_EXP == 3) {
+        hi = u32x2{__builtin_bit_cast(uint32_t, ra[R][j].x), __builtin_bit_cast(uint32_t, ra[R][j].y)};
+        mid = lo = u32x2{__builtin_bit_cast(uint32_t, ra[R][j].z), __builtin_bit_cast(uint32_t, ra[R][j].w)};
+      } else {
+        split3(ra[R][j], hi, mid, lo);
+      }
+      unsigned char *d = base + adst + j * ((BM / 2) * B3_RS);
+      *reinterpret_cast<u32x2 *>(d) = hi;
+      *reinterpret_cast<u32x2 *>(d + 32) = mid;
+      *reinterpret_cast<u32x2 *>(d + 64) = lo;
+    }
+    if (what < 2) return;
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+      if (q + 1 < NP || wlast) *reinterpret_cast<u32x4 *>(base + wdstp[q]) = rb[R][q];
+  };
+
+  f32x16 acc[NT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  };
+  // as in k_gemm: the W fragment is the MFMA's first operand, so a lane ends up with row m = l & 31 and four
+  // consecutive columns per register quad
+  auto flush = [&](int tile, bool whole, int slot) {
+    const int ml = w * 32 + (l & 31), m = tile * BM + ml;
+    float *pt = g.part + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + slot) * (BM * BN) + ml * BN;
+    float *cr = g.C + (size_t)m * g.ldc + n0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = nt * 32 + 8 * q + 4 * (l >> 5);
+        f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+        if (whole) {
+          if (g.bias) v += ldg4(g.bias + n0 + nl);
+          if (m < g.M) *reinterpret_cast<f32x4 *>(cr + nl) = v;
+        } else {
+          *reinterpret_cast<f32x4 *>(pt + nl) = v;
+        }
+      }
+    }
+  };
+
+  // fragments: lane l holds k = 8 (l >> 5) .. +7 of row (l & 31), one ds_read_b128 per part
+  bf16x8 fa[2][3], fw[2][3];
+  const int frag = (l & 31) * B3_RS + (((l >> 5) ^ ((l >> 3) & 1)) * 16);
+  auto read_a = [&](int stage, int slot) {
+    const unsigned char *s = b3_lds + stage * B3_STAGE + w * 32 * B3_RS + frag;
+#pragma unroll
+    for (int part = 0; part < 3; ++part) fa[slot][part] = *reinterpret_cast<const bf16x8 *>(s + part * 32);
+  };
+  auto read_w = [&](int stage, int nt, int slot) {
+    const unsigned char *s = b3_lds + stage * B3_STAGE + B3_A_BYTES + nt * 32 * B3_RS + frag;
+#pragma unroll
+    for (int part = 0; part < 3; ++part) fw[slot][part] = *reinterpret_cast<const bf16x8 *>(s + part * 32);
+  };
+
+  int tile_l = u0 / KT, kt_l = u0 - tile_l * KT;
+  int tile_c = tile_l, kt_c = kt_l, seg_kt0 = kt_l;
+  bool seg_first = true;
+  auto load_next = [&](auto set, int which) {
+    gload(kt_l, set, which);
+    if (which >= 0 && which != 1 + NP) return;  // the cursor moves behind the unit's last load
+    if (++kt_l == KT) {
+      kt_l = 0;
+      ++tile_l;
+      if (tile_l < g.ntiles) setrow(tile_l);
+    }
+  };
+  // One unit = one K tile of 16 = five groups (one per 32-column tile) of six MFMAs, 30 matrix instructions of 32
+  // cycles each.  A wave issues in order and an MFMA occupies the issue port for 8 of its 32 cycles, so everything
+  // else a unit needs is cut into fillers of <= 5 vector instructions and placed one behind each MFMA, where it
+  // issues in the MFMA's shadow (bunched in front of a group instead, the two waves of a SIMD — which the unit's
+  // barrier keeps in step — both leave the matrix pipe idle at the same time: 57 % busy measured).  Behind MFMA k of
+  // group n:
+  //   k = 0          the W fragments of the next group (n = 4: of the next unit's group 0)
+  //   n = 0, 1       k = 1..5: split of A float4 n of unit i + 1 (one bf16 level of one pair per filler), stores at k = 5
+  //   n = 2          k = 1, 2: the two W pieces of unit i + 1 to LDS
+  //   n = 3          k = 1: the unit's barrier, then the next unit's A fragments; k = 2..5: the global loads of unit
+  //                  i + 3, one instruction per filler
+  // sched_barrier pins the order.  Ten groups make one period of the fragment slots, so the loop body is two units.
+  // (No `i + 1 < nu` conditions: a unit past the run's end is loaded from clamped, valid addresses, written to the
+  // idle stage and never used — with every path issuing the same loads the compiler's vmcnt for the older register
+  // set leaves the younger set's loads in flight.)
+  float sr[4];
+  uint32_t so[3][2];
+  auto split_step = [&](int lvl, int h) {
+    const uint32_t pk = pk_bf16(sr[2 * h], sr[2 * h + 1]);
+    so[lvl][h] = pk;
+    if (lvl < 2) {
+      asm("v_sub_f32 %0, %0, %1" : "+v"(sr[2 * h]) : "v"(pk << 16));
+      asm("v_sub_f32 %0, %0, %1" : "+v"(sr[2 * h + 1]) : "v"(pk & 0xffff0000u));
+    }
+  };
+#if B3_EXP == 9
+  unsigned long long stamp_acc[8] = {}, stamp_last = 0;
+#define B3_STAMP(slot)                                              \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();   \
+    stamp_acc[slot] += now_ - stamp_last;                           \
+    stamp_last = now_;                                              \
+  } while (0)
+#else
+#define B3_STAMP(slot)
+#endif
+  auto unit = [&](int i, auto parity) {
+    constexpr int P = decltype(parity)::value, R = P ^ 1;
+    const int st = P;
+    unsigned char *nbase = b3_lds + (st ^ 1) * B3_STAGE;
+    B3_STAMP(4);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int gslot = (P * NT + nt) & 1;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        // smallest terms first
+        const int wp = k == 0 ? 2 : (k == 2 || k == 3) ? 1 : 0, ap = k == 1 ? 2 : (k == 2 || k == 4) ? 1 : 0;
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[gslot][wp], fa[P][ap], acc[nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (B3_EXP == 2) continue;
+        if (k == 0) {
+          if (nt + 1 < NT) read_w(st, nt + 1, gslot ^ 1);
+          else read_w(st ^ 1, 0, gslot ^ 1);
+        } else if (nt < 2 && B3_EXP != 1) {
+          if (k == 1) sr[0] = ra[R][nt].x, sr[1] = ra[R][nt].y, sr[2] = ra[R][nt].z, sr[3] = ra[R][nt].w;
+          if (k < 5) {
+            split_step((k - 1) >> 1, (k - 1) & 1);
+          } else {
+            split_step(2, 0);
+            split_step(2, 1);
+            unsigned char *d = nbase + adst + nt * ((BM / 2) * B3_RS);
+            *reinterpret_cast<u32x2 *>(d) = u32x2{so[0][0], so[0][1]};
+            *reinterpret_cast<u32x2 *>(d + 32) = u32x2{so[1][0], so[1][1]};
+            *reinterpret_cast<u32x2 *>(d + 64) = u32x2{so[2][0], so[2][1]};
+          }
+        } else if (nt == 2 && B3_EXP != 1) {
+          if (k >= 1 && k <= NP && (k < NP || wlast)) *reinterpret_cast<u32x4 *>(nbase + wdstp[k - 1]) = rb[R][k - 1];
+        } else if (nt == 3) {
+          if (k == 1) {
+            if (B3_EXP != 1 && B3_EXP != 5) __syncthreads();
+            read_a(st ^ 1, P ^ 1);
+          }
+          if (k >= 2 && B3_EXP != 4) load_next(std::integral_constant<int, R>(), k - 2);
+        } else if (nt == 4 && k + 3 <= 1 + NP && B3_EXP != 4) {
+          load_next(std::integral_constant<int, R>(), k + 3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#if B3_EXP == 9
+        if (nt == 3 && k < 3) B3_STAMP(5 + k);  // behind the W fragment reads / the barrier / the global loads
+#endif
+      }
+      B3_STAMP(nt);
+    }
+    if (kt_c == KT - 1 || i == nu - 1) {
+      flush(tile_c, seg_kt0 == 0 && kt_c == KT - 1, seg_first ? 0 : 1);
+      zero_acc();
+      seg_first = false;
+      seg_kt0 = 0;
+    }
+    if (++kt_c == KT) kt_c = 0, ++tile_c;
+  };
+  setrow(tile_l);
+  load_next(std::integral_constant<int, 0>(), -1);
+  lstore(0, std::integral_constant<int, 0>(), 3);
+  __syncthreads();
+  load_next(std::integral_constant<int, 1>(), -1);
+  load_next(std::integral_constant<int, 0>(), -1);
+  read_a(0, 0);
+  read_w(0, 0, 0);
+  zero_acc();
+  int i = 0;
+  for (; i + 1 < nu; i += 2) {
+    unit(i, std::integral_constant<int, 0>());
+    unit(i + 1, std::integral_constant<int, 1>());
+  }
+  if (i < nu) unit(i, std::integral_constant<int, 0>());
+#if B3_EXP == 9
+  if (blockIdx.x == 3 && (t == 0 || t == B3_T - 64))
+    printf("b3 stamps wave %d units %d: g0 %llu g1 %llu g2 %llu g3: reads %llu barrier %llu loads %llu rest %llu g4 %llu (cycles per unit)\n", w, nu,
+           stamp_acc[0] / nu, stamp_acc[1] / nu, stamp_acc[2] / nu, stamp_acc[5] / nu, stamp_acc[6] / nu, stamp_acc[7] / nu, stamp_acc[3] / nu, (stamp_acc[4] - stamp_last) / nu);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -744,6 +1088,38 @@ __global__ void k_act(const float *probs, float *action_input, ActStr as, uint64
     if (e_ != hipSuccess) return sf::fail(SF_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// f32 -> bf16, round to nearest even (finite inputs: weights)
+static uint16_t bf16_rn(float x) {
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)((u >> 16) | ((u & 0xffffu) ? 0x40u : 0u));
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf16_f32(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float x;
+  std::memcpy(&x, &u, 4);
+  return x;
+}
+// W [N][K] (N % 160 == 0, K % 16 == 0) -> k_gemm_b3's image: [N / 160][K / 16][160][3 parts][16] bf16
+static std::vector<uint16_t> split_weights(const float *W, int N, int K) {
+  std::vector<uint16_t> img((size_t)N * K * 3);
+  const int KT = K / B3_BK;
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
+      const float x = W[(size_t)n * K + k];
+      const uint16_t hi = bf16_rn(x);
+      const float r1 = x - bf16_f32(hi);
+      const uint16_t mid = bf16_rn(r1);
+      const float r2 = r1 - bf16_f32(mid);
+      const uint16_t lo = bf16_rn(r2);
+      const size_t rec = (((size_t)(n / BN) * KT + k / B3_BK) * BN + n % BN) * 48 + k % B3_BK;
+      img[rec] = hi, img[rec + 16] = mid, img[rec + 32] = lo;
+    }
+  return img;
+}
+
 struct Policy {
   int device = 0, max_agents = 0;
   hipStream_t stream = nullptr;
@@ -751,6 +1127,8 @@ struct Policy {
   // parameters
   float *conv0_wt = nullptr;  // conv0 weights as [c][ky][kx][n] for k_conv0_sparse
   bool dense_conv0 = false;   // SF_POLICY_DENSE_CONV0=1: the implicit-GEMM conv0 instead (A/B, tests)
+  void *conv_w3[4] = {};      // conv1, conv2: the weights split into bf16 hi / mid / lo parts for k_gemm_b3
+  bool f32_conv = false;      // SF_POLICY_F32_CONV=1: conv1, conv2 on the f32 matrix pipe instead (A/B, tests)
   float *conv_w[4] = {}, *gru_w_ih[2] = {}, *gru_w_hh[2] = {}, *gru_b_ih[2] = {}, *gru_b_hh[2] = {};
   float *comb_w = nullptr, *comb_b = nullptr;
   float *res_w[2][3] = {}, *res_b[2][3] = {}, *head_w[2] = {}, *head_b[2] = {};  // [0] policy, [1] value
@@ -802,9 +1180,25 @@ struct Policy {
     if (G != g.ntiles)
       hipLaunchKernelGGL((k_gemm_fixup<WM * 32>), dim3((unsigned)(G - 1), (unsigned)(g.N / BN)), dim3(256), 0, stream, g, KT, G);
   }
+  // the bf16-split form: one 8-wave block per CU
+  template <int MODE>
+  void launch_b3(Gemm g) {
+    const int KT = g.K / B3_BK;
+    g.ntiles = (g.M + B3_BM - 1) / B3_BM;
+    g.part = part;
+    const long units = (long)g.ntiles * KT;
+    const int resident = sk_blocks / 2 * B3_BLOCKS_PER_CU;
+    int G = g.ntiles;
+    if (g.N == BN && units >= 4L * resident) G = resident;
+    g.unit_base = (int)(units / G), g.unit_rem = (int)(units % G);
+    hipLaunchKernelGGL((k_gemm_b3<MODE>), dim3((unsigned)G, (unsigned)(g.N / BN)), dim3(B3_T), B3_LDS, stream, g);
+    if (G != g.ntiles)
+      hipLaunchKernelGGL((k_gemm_fixup<B3_BM>), dim3((unsigned)(G - 1), (unsigned)(g.N / BN)), dim3(256), 0, stream, g, KT, G);
+  }
   template <int MODE>
   void launch_m(const Gemm &g) {
-    if (g.M >= 16384) launch_t<4, 1, 32, MODE>(g);
+    if (g.W3 && MODE != MODE_NCHW) launch_b3<MODE == MODE_NCHW ? MODE_NHWC : MODE>(g);
+    else if (g.M >= 16384) launch_t<4, 1, 32, MODE>(g);
     else launch_t<1, 5, 32, MODE>(g);
   }
   int gemm(const Gemm &g, int mode) {
@@ -841,9 +1235,10 @@ struct Policy {
     Gemm g{A, W, bias, C, M, N, K, lda, ldc, 0, 0, 0, 0, 0, 0, nullptr, A2, W2, bias2, C2};
     return gemm(g, MODE_DENSE);
   }
-  int conv(const float *in, const float *W, float *outp, int agents, int S, int Cin, int nchw) {
+  int conv(const float *in, const float *W, float *outp, int agents, int S, int Cin, int nchw, const void *W3 = nullptr) {
     const int So = (S - 3) / 2 + 1;
-    Gemm g{in, W, nullptr, outp, agents * So * So, HID, Cin * 9, 0, HID, S, Cin, So, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    Gemm g{in, W, nullptr, outp, agents * So * So, HID, Cin * 9, 0, HID, S, Cin, So, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (W3 && g.M >= 16384 && !f32_conv) g.W3 = W3;
     return gemm(g, nchw ? MODE_NCHW : MODE_NHWC);
   }
 };
@@ -898,6 +1293,22 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
         for (int tap = 0; tap < 9; ++tap)
           perm[((size_t)nn * 9 + tap) * HID + c] = w->conv_w[i][((size_t)nn * HID + c) * 9 + tap];
     SFP_TRY(p->upload(&p->conv_w[i], perm.data(), perm.size()));
+    if (i < 3) {
+      const std::vector<uint16_t> img = split_weights(perm.data(), HID, HID * 9);
+      float *d = nullptr;
+      SFP_TRY(p->dalloc(&d, img.size() / 2));
+      SFP_HIP(hipMemcpy(d, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      p->conv_w3[i] = d;
+    }
+  }
+  {
+    const char *e = getenv("SF_POLICY_F32_CONV");
+    p->f32_conv = e && e[0] == '1';
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_b3<MODE_NHWC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)B3_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_b3<MODE_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)B3_LDS) != hipSuccess)
+      SFP_TRY(fail(SF_ERR_DEVICE, "k_gemm_b3 needs 78 KB of LDS per workgroup"));
   }
   for (int g = 0; g < 2; ++g) {
     SFP_TRY(p->upload(&p->gru_w_ih[g], w->gru_w_ih[g], (size_t)G3 * HID));
@@ -960,8 +1371,8 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
   } else {
     hipLaunchKernelGGL(k_conv0_sparse, dim3((unsigned)(agents < p->sk_blocks / 2 ? agents : p->sk_blocks / 2)), dim3(C0_T), C0_LDS, st, d_obs, p->conv0_wt, p->act[0], agents);
   }
-  if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, HID, 0))) return rc;
-  if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, HID, 0))) return rc;
+  if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, HID, 0, p->conv_w3[1]))) return rc;
+  if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, HID, 0, p->conv_w3[2]))) return rc;
   if ((rc = p->conv(p->act[2], p->conv_w[3], p->feat, agents, 3, HID, 0))) return rc;
   float *const none = nullptr;
   hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->feat, p->feat_n, none, agents);               // :108
@@ -1051,6 +1462,25 @@ int sf_policy_gemm(sf_policy *pp, const float *d_a, int32_t lda, const float *d_
   if (lda % 4 || ldc % 4 || lda < k || ldc < n) return sfp::fail(SF_ERR_ARG, "policy gemm: bad leading dimension");
   SFP_HIP(hipSetDevice(p->device));
   return p->dense(d_a, lda, d_w, d_bias, d_c, ldc, m, n, k);
+}
+
+int sf_policy_gemm_split(sf_policy *pp, const float *d_a, int32_t lda, const float *d_w, const float *d_bias, float *d_c,
+                         int32_t ldc, int32_t m, int32_t n, int32_t k) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p || !d_a || !d_w || !d_c) return sfp::fail(SF_ERR_ARG, "null argument");
+  if (lda % 4 || ldc % 4 || lda < k || ldc < n) return sfp::fail(SF_ERR_ARG, "policy gemm: bad leading dimension");
+  if (k % 32 || n % sfp::BN || m < 1) return sfp::fail(SF_ERR_ARG, "policy gemm: unsupported shape");
+  SFP_HIP(hipSetDevice(p->device));
+  void *img = nullptr;
+  if (hipMalloc(&img, (size_t)n * k * 3 * sizeof(uint16_t)) != hipSuccess) return sfp::fail(SF_ERR_MEMORY, "hipMalloc failed (split W)");
+  const size_t elems = (size_t)n * k;
+  hipLaunchKernelGGL(sfp::k_split_weights, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, p->stream, d_w,
+                     (uint16_t *)img, n, k);
+  sfp::Gemm g{d_a, d_w, d_bias, d_c, m, n, k, lda, ldc, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, img};
+  int rc = p->gemm(g, sfp::MODE_DENSE);
+  if (hipStreamSynchronize(p->stream) != hipSuccess && !rc) rc = sfp::fail(SF_ERR_DEVICE, "policy gemm (split) failed");
+  (void)hipFree(img);
+  return rc;
 }
 
 int sf_policy_get_memory(sf_policy *pp, int32_t agent, float *h, float *action_input) {

@@ -43,7 +43,7 @@ def _memory(pb, B):
     return h, a
 
 
-@pytest.mark.parametrize("B,steps", [(1, 3), (5, 4), (37, 3), (100, 2), (300, 2)])
+@pytest.mark.parametrize("B,steps", [(1, 3), (5, 4), (37, 3), (100, 2), (300, 2), (400, 2)])
 def test_forward_matches_reference(B, steps):
     """B picks the GEMM variant of each layer: 1-wave, 2-wave and 4-wave blocks, ragged last tiles."""
     rng = np.random.default_rng(B)
@@ -211,6 +211,58 @@ def test_gemm_kernel_matches_torch(M, N, K):
     want = a.astype(np.float64) @ w.astype(np.float64).T + bias
     bound = 2e-6 * (np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T) + 1e-6
     assert (np.abs(dc.cpu().numpy() - want) <= bound).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 160, 32), (300, 160, 160), (20000, 160, 352), (70001, 320, 288),
+                                   (70001, 160, 288), (200704, 160, 1440), (36864, 160, 1440), (5001, 160, 1440)])
+def test_split_gemm_kernel_matches_float64(M, N, K):
+    """k_gemm_b3 alone (every f32 operand as three bf16 parts, six bf16 MFMAs per block: conv1 / conv2's kernel) vs a
+    float64 matmul on the CPU, same bound as the f32 kernel: |err| <= 2e-6 * sum|a*b|.  One run per tile and the stream-K
+    split, ragged M, two column strips; operands spanning 2^+-20 so that all three parts of a number matter."""
+    pb = policy.PolicyBatch(policy.init_parameters(0), 4)
+    rng = np.random.default_rng(M + 1)
+    a = (rng.normal(size=(M, K)) * np.exp2(rng.integers(-20, 20, size=(M, 1)))).astype(np.float32)
+    w = (rng.normal(size=(N, K)) * np.exp2(rng.integers(-20, 20, size=(N, 1)))).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    da, dw, db = _dev(a), _dev(w), _dev(bias)
+    dc = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    pb.gemm_split(da.data_ptr(), K, dw.data_ptr(), db.data_ptr(), dc.data_ptr(), N, M, N, K)
+    pb.synchronize()
+    got = dc.cpu().numpy()
+    rows = slice(None) if M <= 70001 else rng.choice(M, size=20000, replace=False)
+    a, got = a[rows], got[rows]
+    want = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    mag = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T
+    err = np.abs(got - want)
+    print("worst |err| / sum|a*b| = %.3g" % float(np.max(err / (mag + 1e-30))))
+    assert (err <= 2e-6 * mag + 1e-6).all()
+
+
+def test_split_and_f32_convolutions_agree():
+    """The network with conv1 / conv2 on the bf16-split kernel (default) and on the f32 kernel (SF_POLICY_F32_CONV=1):
+    same probabilities and value within the tolerance of this file."""
+    rng = np.random.default_rng(5)
+    params = policy.init_parameters(seed=9)
+    B = 2000  # conv1 M = 98 000, conv2 M = 18 000: both on the split kernel
+    obs = _dev(_obs(rng, 50))
+    d_obs = obs[torch.arange(B, device="cuda") % 50].contiguous()
+    out = []
+    for f32 in ("0", "1"):
+        os.environ["SF_POLICY_F32_CONV"] = f32
+        try:
+            pb = policy.PolicyBatch(params, B)
+        finally:
+            del os.environ["SF_POLICY_F32_CONV"]
+        d_probs = torch.zeros((B, 9), dtype=torch.float32, device="cuda")
+        d_value = torch.zeros(B, dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            pb.forward(d_obs.data_ptr(), B, d_probs.data_ptr(), d_value.data_ptr())
+        pb.synchronize()
+        out.append((d_probs.cpu().numpy(), d_value.cpu().numpy()))
+        pb.close()
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=RTOL, atol=ATOL)
+    assert not np.array_equal(out[0][0], out[1][0])  # two different kernels did run
 
 
 def test_hip_path_reproduces_the_committed_vectors():
