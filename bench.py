@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 PREROLL = 400  # untimed steps before --warmup (steady-state populations: a zombie every 20 steps, an NPC every 25)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: f32-input MFMA (v_mfma_f32_32x32x2_f32), dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: bf16 MFMA, dense (never the 2:1-sparsity figure)
 
 
 def algorithmic_bytes_per_step(cfg, observe=False):
@@ -353,9 +354,10 @@ def main():
         closed_loop(pol_n)
         pe[1].record()
         torch.cuda.synchronize()
-        g_ms, g_flop, g_n = pb.kernel_time(False)
-        pol = {"loop_ms": pe[0].elapsed_time(pe[1]) / pol_n, "gemm_ms": g_ms / pol_n, "gemm_flop": g_flop / pol_n,
-               "gemm_launches": g_n // pol_n, "steps": pol_n, "agents": agents}
+        (f_ms, f_flop, f_n), (s_ms, s_flop, s_n) = pb.kernel_time_by_pipe(False)
+        pol = {"loop_ms": pe[0].elapsed_time(pe[1]) / pol_n, "gemm_ms": (f_ms + s_ms) / pol_n, "gemm_flop": (f_flop + s_flop) / pol_n,
+               "gemm_launches": (f_n + s_n) // pol_n, "split_ms": s_ms / pol_n, "split_flop": s_flop / pol_n,
+               "split_launches": s_n // pol_n, "f32_ms": f_ms / pol_n, "f32_flop": f_flop / pol_n, "steps": pol_n, "agents": agents}
         pb.close()
 
     if world > 1:
@@ -420,14 +422,22 @@ def main():
                                      "algorithmic_bytes_per_agent_step": 30752 * 4 + 961 * 8},
           }
         if pol:
-            tf = pol["gemm_flop"] / (pol["gemm_ms"] / 1e3) / 1e12
+            # dominant kernel of the network: k_gemm_b3 (conv1, conv2: 92 % of the matrix work), which runs every f32
+            # product as six bf16 products on the bf16 matrix pipe; its roofline is priced in the bf16 flop it executes
+            bf16_tf = 6.0 * pol["split_flop"] / (pol["split_ms"] / 1e3) / 1e12 if pol["split_ms"] > 0 else 0.0
+            f32_tf = pol["f32_flop"] / (pol["f32_ms"] / 1e3) / 1e12 if pol["f32_ms"] > 0 else 0.0
             out["policy"] = {
-                "what": "per rank: observe -> bot-0.5 network (f32, random-init weights; conv0 on the observation's non-zeros, "
-                        "conv1..3 and the dense layers on the f32 MFMA: the roofline below is over those matrix launches) "
-                        "-> sample -> K=1 step, all on device, %d steps" % pol["steps"],
+                "what": "per rank: observe -> bot-0.5 network (f32 results, random-init weights; conv0 on the observation's "
+                        "non-zeros, conv1/conv2 as bf16 hi/mid/lo split products on the bf16 MFMA, conv3 and the dense layers "
+                        "on the f32 MFMA) -> sample -> K=1 step, all on device, %d steps" % pol["steps"],
                 "agent_steps_per_s": world * pol["agents"] / (pol["loop_ms"] / 1e3), "ms_per_step": pol["loop_ms"],
-                "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf / MFMA_F32_PEAK_TFLOPS, "kernel": "k_gemm (%d launches per forward)" % pol["gemm_launches"],
+                "roofline": {"bound": "mfma", "achieved": bf16_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": bf16_tf / MFMA_BF16_PEAK_TFLOPS,
+                             "kernel": "k_gemm_b3 (%d launches per forward; bf16 flop executed = 6 x 2MNK)" % pol["split_launches"],
+                             "ms_per_forward": pol["split_ms"],
+                             "f32_equivalent_tflops": bf16_tf / 6.0,
+                             "f32_mfma_launches": {"achieved": f32_tf, "peak": MFMA_F32_PEAK_TFLOPS, "frac": f32_tf / MFMA_F32_PEAK_TFLOPS,
+                                                   "ms_per_forward": pol["f32_ms"]},
                              "gemm_ms_per_forward": pol["gemm_ms"], "flop_per_agent_forward": pol["gemm_flop"] / pol["agents"]},
             }
         if world == 1 and not args.no_other_configs:

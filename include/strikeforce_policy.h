@@ -87,6 +87,10 @@ int sf_policy_synchronize(sf_policy *p);
  * stream): *ms = summed duration of the MFMA GEMM launches, *flop = their algorithmic flop count
  * (2*M*N*K each), *launches = how many. */
 int sf_policy_kernel_time(sf_policy *p, int32_t enable, float *ms, double *flop, int32_t *launches);
+/* The same, split by matrix pipe: index 0 = launches on the f32 MFMA (k_gemm), index 1 = launches of the bf16-split
+ * kernel (k_gemm_b3: conv1 / conv2 at M >= 16 384).  flop[] is the algorithmic 2*M*N*K in both; the split kernel
+ * executes six bf16 products per algorithmic one. */
+int sf_policy_kernel_time_ex(sf_policy *p, int32_t enable, float ms[2], double flop[2], int32_t launches[2]);
 
 /* The matrix kernel on its own, for unit tests and roofline measurements: C[M][ldc] = A[M][lda] * W[N][K]^T + bias
  * (bias may be NULL), all device pointers, f32; K % 32 == 0, N % 160 == 0, lda % 4 == 0.  Every Linear / GRU gate

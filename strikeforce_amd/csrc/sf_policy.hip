@@ -1,3 +1,14 @@
+  // 32-column tile) of six MFMAs.  The W fragments of group n + 1 are read behind the first MFMA of group n; behind
+  // the second MFMA of group 3 comes the unit's barrier (the loaders have filled the other stage, every compute wave
+  // has read this one) and the read of the next unit's A fragments.  sched_barrier pins the order; ten groups make one
+  // period of the fragment slots, so the loop body is two units.  (Tried instead of the barrier: FULL / FREE counters in
+  // LDS, two and three stages — the compute waves then poll for the loaders, 8 % slower; tools/experiments.)
+  // ----------------------------------------------------------------------------------------------------------
+  // 32-column tile) of six MFMAs.  The W fragments of group n + 1 are read behind the first MFMA of group n; behind
+  // the second MFMA of group 3 comes the unit's barrier (the loaders have filled the other stage, every compute wave
+  // has read this one) and the read of the next unit's A fragments.  sched_barrier pins the order; ten groups make one
+  // period of the fragment slots, so the loop body is two units.
+  // ----------------------------------------------------------------------------------------------------------
 // sf_policy.hip — batched on-device evaluation of the reference's bot network.
 //
 // What is computed, per agent, is AgentModel::forward of StrikeForce-client/bots/bot-0.5/Modules.hpp:54-179:
@@ -354,8 +365,8 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(Gemm g, int KT, int G) {
 //
 // W is split once on the host into the image the LDS wants (one 96-byte record [hi 16][mid 16][lo 16] per (K tile of
 // 16, output column)); activations are split as they are stored to LDS (v_cvt_pk_bf16_f32 + shifts, ~5.5 VALU per
-// element, issued in the gaps of the other wave's MFMAs).  Block tile 256 rows x 160 columns x 16, eight waves of 32
-// rows x 160 columns (two per SIMD), one block per CU, two LDS stages of 39 KB (layout: see `adst` in the kernel).
+// element).  Block tile 256 rows x 160 columns x 16, one block per CU: eight compute waves of 32 rows x 160 columns
+// (two per SIMD) and four loader waves, two LDS stages of 39 KB.
 // Work split, pipeline and tile hand-over (stream-K runs, k_gemm_fixup) as in k_gemm.
 // ---------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -364,17 +375,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef B3_EXP
-#define B3_EXP 0  // tools/r02_b3_exp.sh: ablations of k_gemm_b3 (wrong results, timing only)
-#endif
-#ifndef B3_WAVES
-#define B3_WAVES 8  // waves per block: 4 (128 rows, two blocks per CU) or 8 (256 rows, one block per CU)
-#endif
-constexpr int B3_BM = 32 * B3_WAVES, B3_BK = 16, B3_T = 64 * B3_WAVES, B3_RS = 96;
-constexpr int B3_BLOCKS_PER_CU = 8 / B3_WAVES;
+// 8 compute waves (32 rows x 160 columns each, two per SIMD) + 4 loader waves (one per SIMD)
+constexpr int B3_CW = 8, B3_LW = 4, B3_BM = 32 * B3_CW, B3_BK = 16, B3_T = 64 * (B3_CW + B3_LW), B3_LT = 64 * B3_LW, B3_RS = 96;
 constexpr int B3_A_BYTES = B3_BM * B3_RS, B3_W_BYTES = BN * B3_RS, B3_STAGE = B3_A_BYTES + B3_W_BYTES;
 constexpr int B3_LDS = 2 * B3_STAGE;                 // 79 872 bytes
 constexpr int B3_W_PIECES = BN * 96 / 16;            // 16-byte pieces of one K tile of the W image: 960
+constexpr int B3_SETS = 4;                           // register sets of a loader thread = units in flight from HBM
 
 __device__ inline uint32_t pk_bf16(float a, float b) {
   const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
@@ -418,7 +424,7 @@ __global__ void k_split_weights(const float *W, uint16_t *img, int N, int K) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(B3_T, B3_BLOCKS_PER_CU) void k_gemm_b3(Gemm g) {
+__global__ __launch_bounds__(B3_T, 1) void k_gemm_b3(Gemm g) {
   constexpr int BM = B3_BM, NT = 5;
   extern __shared__ __attribute__((aligned(16))) unsigned char b3_lds[];
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
@@ -427,91 +433,121 @@ __global__ __launch_bounds__(B3_T, B3_BLOCKS_PER_CU) void k_gemm_b3(Gemm g) {
   const int u0 = run_start(g, blockIdx.x);
   const int nu = g.unit_base + ((int)blockIdx.x < g.unit_rem ? 1 : 0);
   if (nu == 0) return;
-
-  // this thread's two float4 of an A tile: rows (t >> 2) and (t >> 2) + 128, k offset 4 * (t & 3)
-  const float *arow[2];
-  auto setrow = [&](int tile) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int m = tile * BM + (t >> 2) + (BM / 2) * j;
-      if (m >= g.M) m = g.M - 1;
-      if (B3_EXP == 6) m &= 255;  // every tile reads the first one: A from L2
-      if (MODE == MODE_DENSE) {
-        arow[j] = g.A + (size_t)m * g.lda + (t & 3) * 4;
-      } else {
-        const int so2 = g.So * g.So;
-        const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
-        arow[j] = g.A + ((size_t)(b * g.S + 2 * oy) * g.S + 2 * ox) * g.Cin + (t & 3) * 4;
-      }
-    }
-  };
-  // its two 16-byte pieces of a W tile (the second one only for t < 448) and where they go in a stage
-  const u32x4 *wimg = reinterpret_cast<const u32x4 *>(g.W3) + (size_t)blockIdx.y * KT * B3_W_PIECES;
-  constexpr int NP = (B3_W_PIECES + B3_T - 1) / B3_T;  // pieces per thread (the last one only on some threads)
-  const bool wlast = t + (NP - 1) * B3_T < B3_W_PIECES;
   // LDS image of a tile: row r = 96 bytes [hi 32][mid 32][lo 32], the two 16-byte k halves of each part swapped on rows
   // with bit 3 set.  Conflict-free for every access: the sixteen rows of a ds_read_b128 lane group land on sixteen
   // different 16-byte slots (6 r mod 16 alone would only reach the eight even ones), four rows of a ds_write_b64 group
   // tile the 128-byte bank window (96 r mod 128 = 0, 96, 64, 32), and the W pieces stay contiguous.
-  auto wdst = [](int piece) { const int n = piece / 6, c = piece % 6; return B3_A_BYTES + n * B3_RS + ((c ^ ((n >> 3) & 1)) * 16); };
-  int wdstp[NP];
+  if (w >= B3_CW) {
+    // ------------------------------------------------------------------------------------------------------
+    // Loader waves.  Unit u's operands go HBM / L2 -> registers (B3_SETS units in flight per thread) -> split -> LDS
+    // stage u & 1, one unit ahead of the compute waves.  What a block moves per unit (16 KB of A + 15 KB of W) is what
+    // bounds this kernel: a CU's vector-memory path delivered ~25 B/clk here (in-kernel stamps: 8 load instructions took
+    // a loader wave ~1300 cycles to issue), about one unit's bytes per unit's MFMA time.  With the same loads, splits and
+    // stores done as fillers between the compute waves' MFMAs, in-order issue put every stall of that path in front of
+    // matrix instructions (57-66 % pipe use); here they stay in these four waves.  Every load is issued whatever the run
+    // length (a unit past the run's end reads clamped, valid addresses and lands in the idle stage): with one static
+    // instruction stream the compiler's vmcnt leaves the younger sets in flight.
+    // ------------------------------------------------------------------------------------------------------
+    const int lt = t - B3_CW * 64;
+    constexpr int AJ = BM * 4 / B3_LT;                          // float4 of A per thread: 4 (rows lt/4 + 64 j)
+    constexpr int NP = (B3_W_PIECES + B3_LT - 1) / B3_LT;       // W pieces per thread: 4 (the last one for lt < 192)
+    const bool wlast = lt + (NP - 1) * B3_LT < B3_W_PIECES;
+    const float *arow[AJ];
+    auto setrow = [&](int tile) {
 #pragma unroll
-  for (int q = 0; q < NP; ++q) wdstp[q] = wdst(t + q * B3_T);
-  const int adst = (t >> 2) * B3_RS + ((((t & 3) >> 1) ^ ((t >> 5) & 1)) * 16) + (t & 1) * 8;
+      for (int j = 0; j < AJ; ++j) {
+        int m = tile * BM + (lt >> 2) + (BM / AJ) * j;
+        if (m >= g.M) m = g.M - 1;
+        if (MODE == MODE_DENSE) {
+          arow[j] = g.A + (size_t)m * g.lda + (lt & 3) * 4;
+        } else {
+          const int so2 = g.So * g.So;
+          const int b = m / so2, r = m - b * so2, oy = r / g.So, ox = r - oy * g.So;
+          arow[j] = g.A + ((size_t)(b * g.S + 2 * oy) * g.S + 2 * ox) * g.Cin + (lt & 3) * 4;
+        }
+      }
+    };
+    const u32x4 *wimg = reinterpret_cast<const u32x4 *>(g.W3) + (size_t)blockIdx.y * KT * B3_W_PIECES;
+    auto wdst = [](int piece) { const int n = piece / 6, c = piece % 6; return B3_A_BYTES + n * B3_RS + ((c ^ ((n >> 3) & 1)) * 16); };
+    int wdstp[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) wdstp[q] = wdst(lt + q * B3_LT);
+    const int adst = (lt >> 2) * B3_RS + ((((lt & 3) >> 1) ^ ((lt >> 5) & 1)) * 16) + (lt & 1) * 8;
 
-  // two register sets: a unit is loaded three units before its MFMAs (two before it is split into LDS) — one unit is
-  // 1.5 us, less than an HBM round trip under load
-  f32x4 ra[2][2];
-  u32x4 rb[2][NP];
-  // one unit's global loads, one instruction per call (`which`: 0, 1 = the A float4, 2.. = the W pieces; -1 = all).
-  // Issued one at a time behind different MFMAs: the CU's address unit takes ~16 cycles per dwordx4 instruction, and
-  // eight waves issuing four each at the same point kept every wave ~900 cycles in that filler (in-order issue).
-  int gl_off = 0;
-  const u32x4 *gl_ws = wimg;
-  auto gload = [&](int kt, auto set, int which) {
-    constexpr int R = decltype(set)::value;
-    if (which <= 0) {
-      int off = kt * B3_BK;
+    f32x4 ra[B3_SETS][AJ];
+    u32x4 rb[B3_SETS][NP];
+    int tile_l = u0 / KT, kt_l = u0 - tile_l * KT;
+    auto load_next = [&](auto set) {
+      constexpr int R = decltype(set)::value;
+      int off = kt_l * B3_BK;
       if (MODE == MODE_NHWC) {
         const int tap = off / g.Cin, c0 = off - tap * g.Cin, ky = tap / 3, kx = tap - ky * 3;
         off = (ky * g.S + kx) * g.Cin + c0;
       }
-      gl_off = off;
-      gl_ws = wimg + (size_t)kt * B3_W_PIECES;
-    }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (which < 0 || which == j) ra[R][j] = ldg4(arow[j] + gl_off);
+      for (int j = 0; j < AJ; ++j) ra[R][j] = ldg4(arow[j] + off);
+      const u32x4 *ws = wimg + (size_t)kt_l * B3_W_PIECES;
 #pragma unroll
-    for (int q = 0; q < NP; ++q)
-      if (which < 0 || which == 2 + q) rb[R][q] = gl_ws[q + 1 < NP || wlast ? t + q * B3_T : t];
-  };
-  // `what`: 0, 1 = the two A float4 (split), 2 = the W pieces; spread over a unit's groups so that no burst of VALU and
-  // LDS stores starves the matrix pipe
-  auto lstore = [&](int stage, auto set, int what) {
-    constexpr int R = decltype(set)::value;
-    unsigned char *base = b3_lds + stage * B3_STAGE;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (what != j && what != 3) continue;
-      u32x2 hi, mid, lo;
-      if (B3_EXP == 3) {
-        hi = u32x2{__builtin_bit_cast(uint32_t, ra[R][j].x), __builtin_bit_cast(uint32_t, ra[R][j].y)};
-        mid = lo = u32x2{__builtin_bit_cast(uint32_t, ra[R][j].z), __builtin_bit_cast(uint32_t, ra[R][j].w)};
-      } else {
-        split3(ra[R][j], hi, mid, lo);
+      for (int q = 0; q < NP; ++q) rb[R][q] = ws[q + 1 < NP || wlast ? lt + q * B3_LT : lt];
+      if (++kt_l == KT) {
+        kt_l = 0;
+        ++tile_l;
+        if (tile_l < g.ntiles) setrow(tile_l);
       }
-      unsigned char *d = base + adst + j * ((BM / 2) * B3_RS);
-      *reinterpret_cast<u32x2 *>(d) = hi;
-      *reinterpret_cast<u32x2 *>(d + 32) = mid;
-      *reinterpret_cast<u32x2 *>(d + 64) = lo;
-    }
-    if (what < 2) return;
+    };
+    auto lstore = [&](int stage, auto set) {
+      constexpr int R = decltype(set)::value;
+      unsigned char *base = b3_lds + stage * B3_STAGE;
 #pragma unroll
-    for (int q = 0; q < NP; ++q)
-      if (q + 1 < NP || wlast) *reinterpret_cast<u32x4 *>(base + wdstp[q]) = rb[R][q];
-  };
+      for (int j = 0; j < AJ; ++j) {
+        u32x2 hi, mid, lo;
+        split3(ra[R][j], hi, mid, lo);
+        unsigned char *d = base + adst + j * ((BM / AJ) * B3_RS);
+        *reinterpret_cast<u32x2 *>(d) = hi;
+        *reinterpret_cast<u32x2 *>(d + 32) = mid;
+        *reinterpret_cast<u32x2 *>(d + 64) = lo;
+      }
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+        if (q + 1 < NP || wlast) *reinterpret_cast<u32x4 *>(base + wdstp[q]) = rb[R][q];
+    };
+    // during unit i (between the barriers of units i - 1 and i): unit i + 1 -> stage (i + 1) & 1, then the loads of
+    // unit i + 1 + B3_SETS into the freed set
+    auto step = [&](int i, auto set) {
+      lstore((i + 1) & 1, set);
+      load_next(set);
+      __syncthreads();
+    };
+    setrow(tile_l);
+    load_next(std::integral_constant<int, 0>());
+    lstore(0, std::integral_constant<int, 0>());
+    load_next(std::integral_constant<int, 1>());
+    load_next(std::integral_constant<int, 2>());
+    load_next(std::integral_constant<int, 3>());
+    load_next(std::integral_constant<int, 0>());
+    __syncthreads();
+    int i = 0;
+    for (; i + 3 < nu; i += 4) {
+      step(i, std::integral_constant<int, 1>());
+      step(i + 1, std::integral_constant<int, 2>());
+      step(i + 2, std::integral_constant<int, 3>());
+      step(i + 3, std::integral_constant<int, 0>());
+    }
+    if (i < nu) step(i, std::integral_constant<int, 1>());
+    if (i + 1 < nu) step(i + 1, std::integral_constant<int, 2>());
+    if (i + 2 < nu) step(i + 2, std::integral_constant<int, 3>());
+    return;
+  }
 
+  // ----------------------------------------------------------------------------------------------------------
+  // Compute waves: fragments from LDS and MFMAs, nothing else.  One unit = one K tile of 16 = five groups (one per
+  // 32-column tile) of six MFMAs.  The W fragments of group n + 1 are read behind the first MFMA of group n; behind
+  // the first MFMA of group 4 the wave releases the stage it has now read completely, checks that the loaders have
+  // filled the other one and reads the next unit's first fragments.  No barrier: with one per unit, the two waves
+  // of a SIMD met at it with nothing queued and the matrix pipe drained once per unit (232 -> 205 TFLOP/s f32-equivalent
+  // with the loaders switched off, against 306 for the same loop without the barrier).  sched_barrier pins the
+  // order; ten groups make one period of the fragment slots, so the loop body is two units.
+  // ----------------------------------------------------------------------------------------------------------
   f32x16 acc[NT];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -540,7 +576,6 @@ __global__ __launch_bounds__(B3_T, B3_BLOCKS_PER_CU) void k_gemm_b3(Gemm g) {
       }
     }
   };
-
   // fragments: lane l holds k = 8 (l >> 5) .. +7 of row (l & 31), one ds_read_b128 per part
   bf16x8 fa[2][3], fw[2][3];
   const int frag = (l & 31) * B3_RS + (((l >> 5) ^ ((l >> 3) & 1)) * 16);
@@ -554,60 +589,11 @@ __global__ __launch_bounds__(B3_T, B3_BLOCKS_PER_CU) void k_gemm_b3(Gemm g) {
 #pragma unroll
     for (int part = 0; part < 3; ++part) fw[slot][part] = *reinterpret_cast<const bf16x8 *>(s + part * 32);
   };
-
-  int tile_l = u0 / KT, kt_l = u0 - tile_l * KT;
-  int tile_c = tile_l, kt_c = kt_l, seg_kt0 = kt_l;
+  int tile_c = u0 / KT, kt_c = u0 - tile_c * KT, seg_kt0 = kt_c;
   bool seg_first = true;
-  auto load_next = [&](auto set, int which) {
-    gload(kt_l, set, which);
-    if (which >= 0 && which != 1 + NP) return;  // the cursor moves behind the unit's last load
-    if (++kt_l == KT) {
-      kt_l = 0;
-      ++tile_l;
-      if (tile_l < g.ntiles) setrow(tile_l);
-    }
-  };
-  // One unit = one K tile of 16 = five groups (one per 32-column tile) of six MFMAs, 30 matrix instructions of 32
-  // cycles each.  A wave issues in order and an MFMA occupies the issue port for 8 of its 32 cycles, so everything
-  // else a unit needs is cut into fillers of <= 5 vector instructions and placed one behind each MFMA, where it
-  // issues in the MFMA's shadow (bunched in front of a group instead, the two waves of a SIMD — which the unit's
-  // barrier keeps in step — both leave the matrix pipe idle at the same time: 57 % busy measured).  Behind MFMA k of
-  // group n:
-  //   k = 0          the W fragments of the next group (n = 4: of the next unit's group 0)
-  //   n = 0, 1       k = 1..5: split of A float4 n of unit i + 1 (one bf16 level of one pair per filler), stores at k = 5
-  //   n = 2          k = 1, 2: the two W pieces of unit i + 1 to LDS
-  //   n = 3          k = 1: the unit's barrier, then the next unit's A fragments; k = 2..5: the global loads of unit
-  //                  i + 3, one instruction per filler
-  // sched_barrier pins the order.  Ten groups make one period of the fragment slots, so the loop body is two units.
-  // (No `i + 1 < nu` conditions: a unit past the run's end is loaded from clamped, valid addresses, written to the
-  // idle stage and never used — with every path issuing the same loads the compiler's vmcnt for the older register
-  // set leaves the younger set's loads in flight.)
-  float sr[4];
-  uint32_t so[3][2];
-  auto split_step = [&](int lvl, int h) {
-    const uint32_t pk = pk_bf16(sr[2 * h], sr[2 * h + 1]);
-    so[lvl][h] = pk;
-    if (lvl < 2) {
-      asm("v_sub_f32 %0, %0, %1" : "+v"(sr[2 * h]) : "v"(pk << 16));
-      asm("v_sub_f32 %0, %0, %1" : "+v"(sr[2 * h + 1]) : "v"(pk & 0xffff0000u));
-    }
-  };
-#if B3_EXP == 9
-  unsigned long long stamp_acc[8] = {}, stamp_last = 0;
-#define B3_STAMP(slot)                                              \
-  do {                                                              \
-    const unsigned long long now_ = __builtin_readcyclecounter();   \
-    stamp_acc[slot] += now_ - stamp_last;                           \
-    stamp_last = now_;                                              \
-  } while (0)
-#else
-#define B3_STAMP(slot)
-#endif
   auto unit = [&](int i, auto parity) {
-    constexpr int P = decltype(parity)::value, R = P ^ 1;
+    constexpr int P = decltype(parity)::value;
     const int st = P;
-    unsigned char *nbase = b3_lds + (st ^ 1) * B3_STAGE;
-    B3_STAMP(4);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int gslot = (P * NT + nt) & 1;
@@ -617,39 +603,15 @@ __global__ __launch_bounds__(B3_T, B3_BLOCKS_PER_CU) void k_gemm_b3(Gemm g) {
         const int wp = k == 0 ? 2 : (k == 2 || k == 3) ? 1 : 0, ap = k == 1 ? 2 : (k == 2 || k == 4) ? 1 : 0;
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[gslot][wp], fa[P][ap], acc[nt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (B3_EXP == 2) continue;
         if (k == 0) {
           if (nt + 1 < NT) read_w(st, nt + 1, gslot ^ 1);
           else read_w(st ^ 1, 0, gslot ^ 1);
-        } else if (nt < 2 && B3_EXP != 1) {
-          if (k == 1) sr[0] = ra[R][nt].x, sr[1] = ra[R][nt].y, sr[2] = ra[R][nt].z, sr[3] = ra[R][nt].w;
-          if (k < 5) {
-            split_step((k - 1) >> 1, (k - 1) & 1);
-          } else {
-            split_step(2, 0);
-            split_step(2, 1);
-            unsigned char *d = nbase + adst + nt * ((BM / 2) * B3_RS);
-            *reinterpret_cast<u32x2 *>(d) = u32x2{so[0][0], so[0][1]};
-            *reinterpret_cast<u32x2 *>(d + 32) = u32x2{so[1][0], so[1][1]};
-            *reinterpret_cast<u32x2 *>(d + 64) = u32x2{so[2][0], so[2][1]};
-          }
-        } else if (nt == 2 && B3_EXP != 1) {
-          if (k >= 1 && k <= NP && (k < NP || wlast)) *reinterpret_cast<u32x4 *>(nbase + wdstp[k - 1]) = rb[R][k - 1];
-        } else if (nt == 3) {
-          if (k == 1) {
-            if (B3_EXP != 1 && B3_EXP != 5) __syncthreads();
-            read_a(st ^ 1, P ^ 1);
-          }
-          if (k >= 2 && B3_EXP != 4) load_next(std::integral_constant<int, R>(), k - 2);
-        } else if (nt == 4 && k + 3 <= 1 + NP && B3_EXP != 4) {
-          load_next(std::integral_constant<int, R>(), k + 3);
+        } else if (nt == 3 && k == 1) {
+          __syncthreads();
+          read_a(st ^ 1, P ^ 1);
         }
         __builtin_amdgcn_sched_barrier(0);
-#if B3_EXP == 9
-        if (nt == 3 && k < 3) B3_STAMP(5 + k);  // behind the W fragment reads / the barrier / the global loads
-#endif
       }
-      B3_STAMP(nt);
     }
     if (kt_c == KT - 1 || i == nu - 1) {
       flush(tile_c, seg_kt0 == 0 && kt_c == KT - 1, seg_first ? 0 : 1);
@@ -659,12 +621,7 @@ __global__ __launch_bounds__(B3_T, B3_BLOCKS_PER_CU) void k_gemm_b3(Gemm g) {
     }
     if (++kt_c == KT) kt_c = 0, ++tile_c;
   };
-  setrow(tile_l);
-  load_next(std::integral_constant<int, 0>(), -1);
-  lstore(0, std::integral_constant<int, 0>(), 3);
   __syncthreads();
-  load_next(std::integral_constant<int, 1>(), -1);
-  load_next(std::integral_constant<int, 0>(), -1);
   read_a(0, 0);
   read_w(0, 0, 0);
   zero_acc();
@@ -674,11 +631,6 @@ __global__ __launch_bounds__(B3_T, B3_BLOCKS_PER_CU) void k_gemm_b3(Gemm g) {
     unit(i + 1, std::integral_constant<int, 1>());
   }
   if (i < nu) unit(i, std::integral_constant<int, 0>());
-#if B3_EXP == 9
-  if (blockIdx.x == 3 && (t == 0 || t == B3_T - 64))
-    printf("b3 stamps wave %d units %d: g0 %llu g1 %llu g2 %llu g3: reads %llu barrier %llu loads %llu rest %llu g4 %llu (cycles per unit)\n", w, nu,
-           stamp_acc[0] / nu, stamp_acc[1] / nu, stamp_acc[2] / nu, stamp_acc[5] / nu, stamp_acc[6] / nu, stamp_acc[7] / nu, stamp_acc[3] / nu, (stamp_acc[4] - stamp_last) / nu);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1141,8 +1093,9 @@ struct Policy {
   // timing of the GEMM launches
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<char> event_split;  // per event: the launch went to the bf16-split kernel
   size_t used_events = 0;
-  double flop = 0;
+  double flop = 0, flop_split = 0;
 
   ~Policy() {
     for (void *p : owned) (void)hipFree(p);
@@ -1187,7 +1140,7 @@ struct Policy {
     g.ntiles = (g.M + B3_BM - 1) / B3_BM;
     g.part = part;
     const long units = (long)g.ntiles * KT;
-    const int resident = sk_blocks / 2 * B3_BLOCKS_PER_CU;
+    const int resident = sk_blocks / 2;  // one block per CU
     int G = g.ntiles;
     if (g.N == BN && units >= 4L * resident) G = resident;
     g.unit_base = (int)(units / G), g.unit_rem = (int)(units % G);
@@ -1210,10 +1163,13 @@ struct Policy {
         SFP_HIP(hipEventCreate(&a));
         SFP_HIP(hipEventCreate(&b));
         events.emplace_back(a, b);
+        event_split.push_back(0);
       }
       e0 = events[used_events].first, e1 = events[used_events].second;
       ++used_events;
-      flop += 2.0 * g.M * g.N * g.K * (g.A2 ? 2 : 1);
+      const bool split = g.W3 && mode != MODE_NCHW;
+      event_split[used_events - 1] = split ? 1 : 0;
+      (split ? flop_split : flop) += 2.0 * g.M * g.N * g.K * (g.A2 ? 2 : 1);
       SFP_HIP(hipEventRecord(e0, stream));
     }
     switch (mode) {
@@ -1520,23 +1476,39 @@ int sf_policy_synchronize(sf_policy *pp) {
   return SF_OK;
 }
 
-int sf_policy_kernel_time(sf_policy *pp, int32_t enable, float *ms, double *flop, int32_t *launches) {
+int sf_policy_kernel_time_ex(sf_policy *pp, int32_t enable, float ms[2], double flop[2], int32_t launches[2]) {
   Policy *p = reinterpret_cast<Policy *>(pp);
   if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
   SFP_HIP(hipSetDevice(p->device));
   SFP_HIP(hipStreamSynchronize(p->stream));
-  float total = 0.f;
+  float total[2] = {0.f, 0.f};
+  int32_t n[2] = {0, 0};
   for (size_t i = 0; i < p->used_events; ++i) {
     float t = 0.f;
     SFP_HIP(hipEventElapsedTime(&t, p->events[i].first, p->events[i].second));
-    total += t;
+    total[p->event_split[i] ? 1 : 0] += t;
+    ++n[p->event_split[i] ? 1 : 0];
   }
-  if (ms) *ms = total;
-  if (flop) *flop = p->flop;
-  if (launches) *launches = (int32_t)p->used_events;
+  for (int k = 0; k < 2; ++k) {
+    if (ms) ms[k] = total[k];
+    if (flop) flop[k] = k ? p->flop_split : p->flop;
+    if (launches) launches[k] = n[k];
+  }
   p->used_events = 0;
-  p->flop = 0;
+  p->flop = p->flop_split = 0;
   p->timing = enable != 0;
+  return SF_OK;
+}
+
+int sf_policy_kernel_time(sf_policy *pp, int32_t enable, float *ms, double *flop, int32_t *launches) {
+  float m[2];
+  double f[2];
+  int32_t n[2];
+  const int rc = sf_policy_kernel_time_ex(pp, enable, m, f, n);
+  if (rc) return rc;
+  if (ms) *ms = m[0] + m[1];
+  if (flop) *flop = f[0] + f[1];
+  if (launches) *launches = n[0] + n[1];
   return SF_OK;
 }
 

@@ -120,6 +120,7 @@ def _bind(L):
     L.sf_policy_gemm.argtypes = [vp, vp, C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.sf_policy_gemm_split.argtypes = L.sf_policy_gemm.argtypes
     L.sf_policy_kernel_time.argtypes = [vp, C.c_int32, _FP, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.sf_policy_kernel_time_ex.argtypes = L.sf_policy_kernel_time.argtypes
     for n in EXPORTS:
         if n != "sf_policy_destroy":
             getattr(L, n).restype = C.c_int
@@ -129,7 +130,7 @@ def _bind(L):
 # every symbol include/strikeforce_policy.h declares
 EXPORTS = ["sf_policy_create", "sf_policy_destroy", "sf_policy_reset_memory", "sf_policy_reset_memory_n", "sf_policy_forward", "sf_policy_act",
            "sf_policy_get_memory", "sf_policy_set_memory", "sf_policy_set_stream", "sf_policy_synchronize",
-           "sf_policy_kernel_time", "sf_policy_gemm", "sf_policy_gemm_split", "sf_policy_abi_version"]
+           "sf_policy_kernel_time", "sf_policy_kernel_time_ex", "sf_policy_gemm", "sf_policy_gemm_split", "sf_policy_abi_version"]
 
 
 class PolicyBatch:
@@ -234,6 +235,12 @@ class PolicyBatch:
         self._ck(self.L.sf_policy_gemm_split(self.h, C.c_void_p(d_a_ptr), lda, C.c_void_p(d_w_ptr),
                                              C.c_void_p(d_bias_ptr) if d_bias_ptr else None, C.c_void_p(d_c_ptr), ldc, m, n, k),
                  "sf_policy_gemm_split")
+
+    def kernel_time_by_pipe(self, enable=True):
+        """[(ms, flop, launches) of the f32-MFMA launches, (...) of the bf16-split launches] since the last call."""
+        ms, fl, n = (C.c_float * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)()
+        self._ck(self.L.sf_policy_kernel_time_ex(self.h, 1 if enable else 0, ms, fl, n), "sf_policy_kernel_time_ex")
+        return [(ms[k], fl[k], n[k]) for k in range(2)]
 
     def kernel_time(self, enable=True):
         """(ms, flop, launches) of the MFMA GEMM launches since the last call; arms / disarms the timers."""
