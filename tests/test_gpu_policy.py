@@ -232,10 +232,10 @@ def test_split_gemm_kernel_matches_float64(M, N, K):
     rows = slice(None) if M <= 70001 else rng.choice(M, size=20000, replace=False)
     a, got = a[rows], got[rows]
     want = a.astype(np.float64) @ w.astype(np.float64).T + bias
-    mag = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T
+    mag = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(bias)  # sum|a*b| + |bias|
     err = np.abs(got - want)
-    print("worst |err| / sum|a*b| = %.3g" % float(np.max(err / (mag + 1e-30))))
-    assert (err <= 2e-6 * mag + 1e-6).all()
+    print("worst |err| / (sum|a*b| + |bias|) = %.3g" % float(np.max(err / mag)))
+    assert (err <= 2e-6 * mag).all()
 
 
 def test_split_and_f32_convolutions_agree():
