@@ -124,27 +124,36 @@ struct Core {
   //   * the power is left as the signed difference lo16 - hi16 of the table product (congruent mod 65537, magnitude
   //     < 2^16); the terms are summed signed and one constant multiple of 65537 makes the total positive before the
   //     single reduction of the sum.
-  static constexpr uint32_t SUM_BIAS = 1u + 181u * 65537u;  // 18 * 10 * 65535 < 181 * 65537
+  //     The constant is spread over the lanes: every lane's product gets SUM_BIAS_LANE added inside the multiply (mad),
+  //     and the 32 lanes of rows 0 and 1 together add 32 * SUM_BIAS_LANE = 383 * 65537 + 1 — the generator's `sum = 1`
+  //     plus a multiple of 65537 that keeps every row's partial sum positive (a row of 16 terms is > -16 * 10 * 65536),
+  //     so every lane's index stays inside the table: x < 2^26, hi16 <= 563 < LOGT_OFF.  The same (even) constant is
+  //     added to the byte offset 2 t, which keeps the load's unsigned register offset non-negative; log_base() moves
+  //     the table pointer down by as much.
+  static constexpr uint32_t SUM_BIAS_LANE = 63489u + 11u * 65537u;  // 32 * 63489 = 31 * 65537 + 1
+  static_assert((32ull * SUM_BIAS_LANE) % 65537ull == 1ull, "the lanes' bias must add up to the generator's +1");
+  static_assert(SUM_BIAS_LANE % 2u == 0u, "it is also a byte offset into a table of 16-bit entries");
+  static_assert(16ull * SUM_BIAS_LANE > 16ull * 10ull * 65536ull, "a row's partial sum must stay positive");
+  static_assert((32ull * SUM_BIAS_LANE + 18ull * 10ull * 65535ull) >> 16 < (unsigned long long)LOGT_OFF, "index below the table");
+  static SF_DEV const uint16_t *log_base(const Params &p) { return p.logt + LOGT_OFF - (int)(SUM_BIAS_LANE / 2u); }
+  static SF_DEV V issue_offset(const uint32_t *xt, V rl, V rs4, V rus, V &d) {
+    const V m4 = W::mul24(rl, rs4);  // 4 * (log * seed); bits above 4 * 65536 are multiples of the group order
+    const V pr = W::pow_pair(xt, m4);
+    d = (pr & 0xffffu) - (pr >> 16);  // == 3^m (mod 65537), in (-65536, 65536)
+    return W::rng_reduce(d, rus, V(SUM_BIAS_LANE));
+  }
   static SF_DEV uint32_t draw_issue(Arena &S, const Params &p) {
-    const V m4 = W::mul24(S.rl, S.rs4);  // 4 * (log * seed); bits above 4 * 65536 are multiples of the group order
-    const V pr = W::pow_pair(S.xt, m4);
-    const V d = (pr & 0xffffu) - (pr >> 16);  // == 3^m (mod 65537), in (-65536, 65536)
-    const V x = W::sum18_row1(S.rus * d) + SUM_BIAS;  // < 2^25 on lanes 16..31
-    const V t = (x & 0xffffu) - (x >> 16);             // == x (mod 65537), in (-512, 65536): the table does the rest
-    // every lane holds a row sum of zero-or-tap terms plus the bias (rows 0, 2, 3 just their own), so every index is
-    // inside the table
-    S.la = W::gload_u16_at(p.logt, (t << 1) + 2u * (uint32_t)LOGT_OFF);
+    V d;
+    S.la = W::gload_u16_at(log_base(p), issue_offset(S.xt, S.rl, S.rs4, S.rus, d));
     const int32_t o = (int32_t)W::readlane(d, 18u);
     return (uint32_t)(o + ((o >> 31) & 65537)) & 1023u;
   }
   static SF_DEV uint32_t draw(Arena &S, const uint8_t *, const Params &p) {  // RN:54-62
     SF_PROF(PH_RNG);
     S.jomle += 1u;
-    // (not reduced mod 2^16: every consumer of the hot state — the 24-bit multiply by the seed, the table offsets,
-    // store() — takes the low 16 bits itself)
-    const V lnew = W::mul24_su(S.jomle & 0xffffu, S.la);
-    const V ln = W::lane();
-    S.rl = W::select((ln == 17u) | (ln == 18u), lnew, W::shl1(S.rl));  // rotate left, new value last (+ copy on 18)
+    // rotate left, new value last (+ copy on 18).  Neither jomle nor the product is reduced mod 2^16: every consumer of
+    // the hot state — the 24-bit multiply by the seed, the table offsets, store() — takes the low 16 bits itself
+    S.rl = W::rng_commit(S.rl, S.jomle, S.la);
     return draw_issue(S, p);  // draw n+1's lookup is now in flight; lane 18's power is draw n's value
   }
 
@@ -172,12 +181,8 @@ struct Core {
   // next one, so that the lookup's latency passes under whatever runs between two calls.  `S.la2` is a pure function
   // of (rl2, warm) and is dropped at store time like `S.la`.
   static SF_DEV void prewarm_issue(Arena &S, const Params &p) {
-    const V m4 = W::mul24(S.rl2, S.rseed2) << 2;
-    const V pr = W::pow_pair(S.xt, m4);
-    const V d = (pr & 0xffffu) - (pr >> 16);
-    const V x = W::sum18_row1(S.rus * d) + SUM_BIAS;
-    const V t = (x & 0xffffu) - (x >> 16);
-    S.la2 = W::gload_u16_at(p.logt, (t << 1) + 2u * (uint32_t)LOGT_OFF);
+    V d;
+    S.la2 = W::gload_u16_at(log_base(p), issue_offset(S.xt, S.rl2, S.rseed2 << 2, S.rus, d));
     S.la2_ok = 1u;
   }
   static SF_DEV void prewarm_one(Arena &S, const Params &p) {

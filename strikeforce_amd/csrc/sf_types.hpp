@@ -131,7 +131,7 @@ struct Params {
 // The log table is indexed by the half-reduced tap sum t = lo16(x) - hi16(x), x < 2^25, i.e. t in (-512, 65536):
 // entry t + LOGT_OFF holds log_3(t mod 65537), and the entry of residue 0 holds log_3(1) = 0, which is RN:58's
 // `sum + (int)(sum == 0)`.  A value v in [1, 65536] is looked up at v + LOGT_OFF.
-constexpr int LOGT_OFF = 512;
+constexpr int LOGT_OFF = 1024;  // >= 532: the largest hi16 of a draw's biased tap sum (sf_core.hpp SUM_BIAS_LANE)
 constexpr int LOGT_ENTRIES = LOGT_OFF + 65537;
 
 // Per-arena scratch bitmaps in LDS, one bit per cell (sf_core.hpp "cell bitmaps"): only with the flag plane in LDS

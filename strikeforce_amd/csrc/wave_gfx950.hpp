@@ -135,6 +135,44 @@ struct WaveGfx950 {
     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
     return r;
   }
+  // --- the generator's hot path, hand-written where the compiler's version carried extra instructions (sf_core.hpp draw()) ---
+  // rl <- (lane 17 or 18) ? e * la : rl of the lane above (wave_shl:1): one multiply and one DPP select.  Only the low
+  // 16 bits of the product matter and they depend on the low 16 bits of e alone, so e needs no mask.
+  static SF_DEV V rng_commit(V rl, uint32_t e, V la) {
+    uint32_t t;
+    asm("v_mul_u32_u24 %[t], %[e], %[la]\n\t"
+        "s_mov_b64 vcc, 0x60000\n\t"
+        "v_cndmask_b32_dpp %[rl], %[rl], %[t], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : [rl] "+v"(rl), [t] "=&v"(t)
+        : [e] "s"(e), [la] "v"(la)
+        : "vcc");
+    return rl;
+  }
+  // x = d * us + bias on every lane, summed like sum18_row1 (row 1 = rows 0 + 1), reduced mod 65537 to
+  // t = lo16 - hi16; returns 2 t + bias, a non-negative byte offset (the caller's table pointer is moved down by
+  // the same constant: the load's 32-bit register offset is unsigned and t can be negative).  One mad, five DPP adds
+  // (each needs two wait states behind the write it reads: s_nop 1, slots the other waves of the SIMD fill), one SDWA
+  // subtract, one shift-add.  `bias` is a vector register holding the same even constant on every lane (a VOP3
+  // instruction takes no literal on gfx9, and scalar registers are the scarcer kind in this kernel).
+  static SF_DEV V rng_reduce(V d, V us, V bias) {
+    uint32_t x;
+    asm("v_mad_i32_i24 %[x], %[d], %[us], %[bias]\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[x], %[x], %[x] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[x], %[x], %[x] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[x], %[x], %[x] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[x], %[x], %[x] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[x], %[x], %[x] row_bcast:15 row_mask:0x2 bank_mask:0xf\n\t"
+        "v_sub_u32_sdwa %[x], %[x], %[x] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+        "v_lshl_add_u32 %[x], %[x], 1, %[bias]"
+        : [x] "=&v"(x)
+        : [d] "v"(d), [us] "v"(us), [bias] "v"(bias));
+    return x;
+  }
   // 3^lo * 3^(256 hi) from the two halves of the power table (1 KiB each, the table 2 KiB-aligned in LDS), for an
   // exponent pre-scaled by 4: the byte offsets are bit fields of m4 OR-ed into the table's address (v_and_or_b32)
   static SF_DEV V pow_pair(const uint32_t *xt, V m4) {

@@ -267,6 +267,29 @@ struct WaveEmu {
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
     return r;
   }
+  static V rng_commit(const V &rl, uint32_t e, const V &la) {
+    EMU_OP();
+    V r;
+    for (int i = 0; i < 63; ++i) r.v[i] = rl.v[i + 1];
+    r.v[63] = 0;
+    r.v[17] = (e & 0xffffffu) * (la.v[17] & 0xffffffu);
+    r.v[18] = (e & 0xffffffu) * (la.v[18] & 0xffffffu);
+    return r;
+  }
+  static V rng_reduce(const V &d, const V &us, const V &bias) {
+    EMU_OP();
+    uint32_t rs[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 64; ++i) {
+      const int32_t a = (int32_t)(d.v[i] << 8) >> 8, b = (int32_t)(us.v[i] << 8) >> 8;  // v_mad_i32_i24: signed 24-bit factors
+      rs[i >> 4] += (uint32_t)(a * b) + bias.v[i];
+    }
+    V r;
+    for (int i = 0; i < 64; ++i) {
+      const uint32_t x = rs[i >> 4] + ((i >> 4) == 1 ? rs[0] : 0u);
+      r.v[i] = (((x & 0xffffu) - (x >> 16)) << 1) + bias.v[i];
+    }
+    return r;
+  }
   static V pow_pair(const uint32_t *xt, const V &m4) {
     EMU_OP();
     V r;
