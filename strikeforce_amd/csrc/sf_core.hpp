@@ -44,7 +44,6 @@ struct Core {
     V ppos;
     // RNG (lane < 18): log_3(random[i]) (bit 16 set: random[i] == 0), us[i], seed[i]  RN:31
     V rl, rus, rseed;
-    V rs4;  // 4 * rseed: the draw's exponent comes out pre-scaled to a byte offset into the power table
     // the NEXT episode's generator, warmed up a few draws per step so that an in-kernel restart does not stall on
     // _srand's 1024 serial draws (RN:73-74): log state, seed digits, draws done so far (0..1024)
     V rl2, rseed2;
@@ -136,15 +135,15 @@ struct Core {
   static_assert(16ull * SUM_BIAS_LANE > 16ull * 10ull * 65536ull, "a row's partial sum must stay positive");
   static_assert((32ull * SUM_BIAS_LANE + 18ull * 10ull * 65535ull) >> 16 < (unsigned long long)LOGT_OFF, "index below the table");
   static SF_DEV const uint16_t *log_base(const Params &p) { return p.logt + LOGT_OFF - (int)(SUM_BIAS_LANE / 2u); }
-  static SF_DEV V issue_offset(const uint32_t *xt, V rl, V rs4, V rus, V &d) {
-    const V m4 = W::mul24(rl, rs4);  // 4 * (log * seed); bits above 4 * 65536 are multiples of the group order
-    const V pr = W::pow_pair(xt, m4);
+  static SF_DEV V issue_offset(const uint32_t *xt, V rl, V rseed, V rus, V &d) {
+    const V m = W::mul24(rl, rseed);  // log * seed; bits above 65536 are multiples of the group order
+    const V pr = W::pow_bytes(xt, m);
     d = (pr & 0xffffu) - (pr >> 16);  // == 3^m (mod 65537), in (-65536, 65536)
     return W::rng_reduce(d, rus, V(SUM_BIAS_LANE));
   }
   static SF_DEV uint32_t draw_issue(Arena &S, const Params &p) {
     V d;
-    S.la = W::gload_u16_at(log_base(p), issue_offset(S.xt, S.rl, S.rs4, S.rus, d));
+    S.la = W::gload_u16_at(log_base(p), issue_offset(S.xt, S.rl, S.rseed, S.rus, d));
     const int32_t o = (int32_t)W::readlane(d, 18u);
     return (uint32_t)(o + ((o >> 31) & 65537)) & 1023u;
   }
@@ -169,7 +168,6 @@ struct Core {
     S.rl = V(RL_ZERO);
     seed_digits(S.rus, us);
     seed_digits(S.rseed, tb, 1u);
-    S.rs4 = S.rseed << 2;
     S.jomle = 18u;
     (void)lds;
     for (int i = 0; i < 1024; ++i) draw_core<false>(S.rl, S.rus, S.rseed, S.jomle, S.xt, p);
@@ -182,7 +180,7 @@ struct Core {
   // of (rl2, warm) and is dropped at store time like `S.la`.
   static SF_DEV void prewarm_issue(Arena &S, const Params &p) {
     V d;
-    S.la2 = W::gload_u16_at(log_base(p), issue_offset(S.xt, S.rl2, S.rseed2 << 2, S.rus, d));
+    S.la2 = W::gload_u16_at(log_base(p), issue_offset(S.xt, S.rl2, S.rseed2, S.rus, d));
     S.la2_ok = 1u;
   }
   static SF_DEV void prewarm_one(Arena &S, const Params &p) {
@@ -1398,7 +1396,7 @@ struct Core {
     S.dirty = 1u;
     if (adopt) {
       prewarm(S, lds, p, 1024u);  // whatever is still missing
-      S.rl = S.rl2, S.rseed = S.rseed2, S.rs4 = S.rseed2 << 2, S.jomle = 18u + 1024u;
+      S.rl = S.rl2, S.rseed = S.rseed2, S.jomle = 18u + 1024u;
       draw_issue(S, p);
     } else {
       srand_(S, lds, p, tb, serial);
@@ -1526,8 +1524,7 @@ struct Core {
       const V rw = W::gload(p.rng + (size_t)a * RNG_WORDS, ln, in);
       const V val = rw & 0xfffffu;
       S.rus = (rw >> 20) & 15u, S.rseed = W::select(ln == 18u, V(1u), (rw >> 24) & 15u);
-      S.rs4 = S.rseed << 2;
-      const P nz = in & (val != 0u);
+        const P nz = in & (val != 0u);
       S.rl = W::select(nz, W::gload_u16(p.logt, val + (uint32_t)LOGT_OFF, nz), V(RL_ZERO));
       const V rw2 = W::gload(p.rng2 + (size_t)a * RNG_WORDS, ln, in);  // log form: never dumped
       S.rl2 = rw2 & 0x1ffffu, S.rseed2 = W::select(ln == 18u, V(1u), rw2 >> 24);

@@ -175,6 +175,18 @@ struct WaveGfx950 {
   }
   // 3^lo * 3^(256 hi) from the two halves of the power table (1 KiB each, the table 2 KiB-aligned in LDS), for an
   // exponent pre-scaled by 4: the byte offsets are bit fields of m4 OR-ed into the table's address (v_and_or_b32)
+  // the same for an unscaled exponent m (bits above 16 ignored): the two table offsets 4 * byte0(m) and 4 * byte1(m) are
+  // one SDWA shift each (a byte select on the operand), against three instructions for the mask / shift / mask form
+  static SF_DEV V pow_bytes(const uint32_t *xt, V m) {
+    typedef const __attribute__((address_space(3))) uint32_t *lptr;
+    const uint32_t base = (uint32_t)(uintptr_t)(lptr)xt;
+    uint32_t oa, ob;
+    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(oa) : "v"(m));
+    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ob) : "v"(m));
+    const uint32_t a = *(lptr)(uintptr_t)(oa | base);
+    const uint32_t b = *((lptr)(uintptr_t)(ob | base) + 256);  // second half: DS offset 1024
+    return mul24(a, b);
+  }
   static SF_DEV V pow_pair(const uint32_t *xt, V m4) {
     typedef const __attribute__((address_space(3))) uint32_t *lptr;
     const uint32_t base = (uint32_t)(uintptr_t)(lptr)xt;

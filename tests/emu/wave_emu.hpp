@@ -290,6 +290,12 @@ struct WaveEmu {
     }
     return r;
   }
+  static V pow_bytes(const uint32_t *xt, const V &m) {
+    EMU_OP();
+    V r;
+    for (int i = 0; i < 64; ++i) r.v[i] = xt[m.v[i] & 255u] * xt[256 + ((m.v[i] >> 8) & 255u)];
+    return r;
+  }
   static V pow_pair(const uint32_t *xt, const V &m4) {
     EMU_OP();
     V r;
