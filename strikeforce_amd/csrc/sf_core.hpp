@@ -144,6 +144,7 @@ struct Core {
   static SF_DEV uint32_t draw_issue(Arena &S, const Params &p) {
     V d;
     S.la = W::gload_u16_at(log_base(p), issue_offset(S.xt, S.rl, S.rseed, S.rus, d));
+    W::rng_prio_end();
     const int32_t o = (int32_t)W::readlane(d, 18u);
     return (uint32_t)(o + ((o >> 31) & 65537)) & 1023u;
   }

@@ -52,6 +52,15 @@ extern __device__ uint32_t sf_diag_buffer[];
 #define SF_STAMP_END(S, a)
 #endif
 
+#ifndef SF_RNG_PRIO
+#define SF_RNG_PRIO 1
+#endif
+#ifndef SF_RNG_PRIO_LEVEL
+#define SF_RNG_PRIO_LEVEL 3
+#endif
+#define SF_STR2(x) #x
+#define SF_STR(x) SF_STR2(x)
+
 struct WaveGfx950 {
   using V = uint32_t;
   using P = bool;
@@ -138,9 +147,20 @@ struct WaveGfx950 {
   // --- the generator's hot path, hand-written where the compiler's version carried extra instructions (sf_core.hpp draw()) ---
   // rl <- (lane 17 or 18) ? e * la : rl of the lane above (wave_shl:1): one multiply and one DPP select.  Only the low
   // 16 bits of the product matter and they depend on the low 16 bits of e alone, so e needs no mask.
+  // SF_RNG_PRIO: 0 = off, 1 = the wave runs at raised priority from the round's first instruction to its last vector
+  // instruction, 2 = until the table load has been issued (rng_prio_end)
+  static SF_DEV void rng_prio_end() {
+#if SF_RNG_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  }
   static SF_DEV V rng_commit(V rl, uint32_t e, V la) {
     uint32_t t;
-    asm("v_mul_u32_u24 %[t], %[e], %[la]\n\t"
+    asm(
+#if SF_RNG_PRIO
+        "s_setprio " SF_STR(SF_RNG_PRIO_LEVEL) "\n\t"
+#endif
+        "v_mul_u32_u24 %[t], %[e], %[la]\n\t"
         "s_mov_b64 vcc, 0x60000\n\t"
         "v_cndmask_b32_dpp %[rl], %[rl], %[t], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
         : [rl] "+v"(rl), [t] "=&v"(t)
@@ -169,6 +189,9 @@ struct WaveGfx950 {
         "v_add_u32_dpp %[x], %[x], %[x] row_bcast:15 row_mask:0x2 bank_mask:0xf\n\t"
         "v_sub_u32_sdwa %[x], %[x], %[x] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
         "v_lshl_add_u32 %[x], %[x], 1, %[bias]"
+#if SF_RNG_PRIO == 1
+        "\n\ts_setprio 0"
+#endif
         : [x] "=&v"(x)
         : [d] "v"(d), [us] "v"(us), [bias] "v"(bias));
     return x;

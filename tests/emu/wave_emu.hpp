@@ -267,6 +267,7 @@ struct WaveEmu {
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
     return r;
   }
+  static void rng_prio_end() {}
   static V rng_commit(const V &rl, uint32_t e, const V &la) {
     EMU_OP();
     V r;
