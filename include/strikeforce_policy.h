@@ -4,9 +4,12 @@
  * (StrikeForce-client/bots/bot-0.5/Agent.hpp:178-214 predict(), Modules.hpp:54-179 AgentModel).  This
  * library evaluates the same network for every agent of an arena batch in one pass on the GPU, reading
  * the observation buffer sf_observe_device() wrote and producing the command chars sf_step_device()
- * consumes, so the 123 KB/agent observation never leaves HBM.  Arithmetic is f32 end to end (f32-input
- * MFMA, f32 accumulate); every agent keeps its own recurrent state exactly as one reference `Agent`
- * object does.  Inference only: the PPO learner (Agent.hpp:270-420) is out of scope.
+ * consumes, so the 123 KB/agent observation never leaves HBM.  Inputs, outputs, state and accumulation are f32;
+ * the matrix products run on the f32-input MFMA or — conv1 and conv2 at 16 384 rows and more — on the bf16
+ * MFMA with every f32 operand split into three bf16 parts, which keeps the error at the level of one f32
+ * rounding per product (|err| <= 2e-6 * sum|a*w| either way; SF_POLICY_F32_CONV=1 in the environment at
+ * sf_policy_create keeps everything on the f32 pipe).  Every agent keeps its own recurrent state exactly as one
+ * reference `Agent` object does.  Inference only: the PPO learner (Agent.hpp:270-420) is out of scope.
  *
  * Same conventions as strikeforce.h: plain pointers and sizes, 0 = success, sf_last_error() for text,
  * no CPU path (SF_ERR_DEVICE without a GPU).
