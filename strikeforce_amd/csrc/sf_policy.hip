@@ -974,6 +974,202 @@ __global__ __launch_bounds__(256) void k_heads(const float *xp, const float *xv,
   if (l == 0) value[a] = sigmoidf_(val);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_tail: everything behind conv2 in one launch (conv3, both GRU cells, combined_processor, the two heads: 7 matrix
+// and 9 row launches before).  One 16-wave workgroup per 16 agents; the activations of those agents stay in LDS from
+// layer to layer, the weights (3 MB in all) stream from L2 once per workgroup straight into MFMA operands.
+//   matrix steps  v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: the same fmaf-chain arithmetic as k_gemm): a wave
+//                 owns 16-column tiles of the [16 agents][N] output; per 16 k it reads one float4 of its agent row
+//                 from LDS and one float4 of its weight row from global memory (lane l: row / column l & 15,
+//                 k = 4 (l >> 4) + j in MFMA j — any fixed permutation of k works as long as both operands use it),
+//                 weight loads kept two batches of ~10 float4 ahead
+//   row steps     one wave per agent, the row kernels' own functions (row_norm, gru_cell) on LDS rows
+// LDS rows that feed a matrix step are K + 8 floats apart: conflict-free for the ds_read_b128 lane groups.
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int TL_R = 16, TL_T = 1024;
+constexpr int TL_LD = HID + 8, TL_LDC = COMB_PAD + 8, TL_LDX = 9 * HID + 8;  // 168, 360, 1448
+constexpr int TL_A = 0;                              // region A: conv3's input rows, later gi / gh / comb, later lin0 / lin1 / x0 / x1
+constexpr int TL_GI = TL_A, TL_GH = TL_A + TL_R * G3, TL_COMB = TL_A + 2 * TL_R * G3;
+constexpr int TL_LIN0 = TL_A, TL_LIN1 = TL_A + TL_R * TL_LD, TL_X0 = TL_COMB, TL_X1 = TL_COMB + TL_R * TL_LD;
+constexpr int TL_B0 = TL_A + TL_R * TL_LDX;          // feat_n
+constexpr int TL_B1 = TL_B0 + TL_R * TL_LD;          // h0, then h1
+constexpr int TL_B2 = TL_B1 + TL_R * TL_LD;          // gated_n
+constexpr int TL_Y0 = TL_B2 + TL_R * TL_LD;          // feat, then gated
+constexpr int TL_FLOATS = TL_Y0 + TL_R * TL_LD;
+constexpr int TL_LDS = TL_FLOATS * 4;                // 135 680 bytes
+static_assert(TL_COMB + TL_R * TL_LDC <= TL_B0 && TL_X1 + TL_R * TL_LD <= TL_B0, "region A holds its tenants");
+
+struct TailArgs {
+  const float *act2, *obs, *conv3_w;
+  const float *gru_w_ih[2], *gru_w_hh[2], *gru_b_ih[2], *gru_b_hh[2];
+  const float *comb_w, *comb_b;
+  const float *res_w[2][3], *res_b[2][3], *head_w[2], *head_b[2];
+  float *h[2];
+  const float *action_input;
+  float *probs, *value;
+  int agents;
+};
+
+// out[r][n0 + c] = bias[n0 + c] + sum_k in[r][k] * W[n0 + c][k] for the 16 agents r and 16 columns c of one tile
+template <int K>
+__device__ inline void tail_tile(const float *in, int ldi, const float *W, const float *bias, float *out, int ldo, int n0, int l) {
+  constexpr int STEPS = K / 16, U = (STEPS % 10 == 0) ? 10 : 11, NBATCH = STEPS / U;
+  static_assert(STEPS % U == 0, "K / 16 must split into whole batches");
+  const int row = l & 15, g = l >> 4;
+  const float *ap = in + row * ldi + 4 * g;
+  const float *wp = W + (size_t)(n0 + row) * K + 4 * g;
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 wq[2][U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) wq[0][u] = ldg4(wp + 16 * u);
+#pragma unroll
+  for (int b = 0; b < NBATCH; ++b) {
+    if (b + 1 < NBATCH) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) wq[(b + 1) & 1][u] = ldg4(wp + 16 * ((b + 1) * U + u));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4 *>(ap + 16 * (b * U + u));
+      const f32x4 w4 = wq[b & 1][u];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w4.w, acc, 0, 0, 0);
+    }
+  }
+  const float bv = bias ? bias[n0 + row] : 0.f;  // lane l holds column n0 + (l & 15) of agents 4 g .. 4 g + 3
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(4 * g + r) * ldo + n0 + row] = acc[r] + bv;
+}
+
+__global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
+  extern __shared__ __attribute__((aligned(16))) float tl[];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int a_raw = blockIdx.x * TL_R + w;
+  const bool valid = a_raw < t.agents;
+  const int a = valid ? a_raw : t.agents - 1;  // a ragged last workgroup computes its missing rows on the last agent, stores nothing
+  // ---- conv3's input (act2 row = 9 pixels x 160 channels, the K order of the permuted weight) and h0
+  {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(t.act2 + (size_t)a * (9 * HID));
+    f32x4 *dst = reinterpret_cast<f32x4 *>(tl + TL_A + w * TL_LDX);
+    for (int i = l; i < 9 * HID / 4; i += 64) dst[i] = src[i];
+    row_store(tl + TL_B1 + w * TL_LD, l, row_load(t.h[0] + (size_t)a * HID, l));
+  }
+  __syncthreads();
+  if (w < HID / 16) tail_tile<9 * HID>(tl + TL_A, TL_LDX, t.conv3_w, nullptr, tl + TL_Y0, TL_LD, 16 * w, l);  // Modules.hpp:66-71
+  __syncthreads();
+  row_store(tl + TL_B0 + w * TL_LD, l, row_norm(row_load(tl + TL_Y0 + w * TL_LD, l)));  // feat_n :108
+  __syncthreads();
+  // ---- gru0: gi = W_ih feat_n + b_ih, gh = W_hh h0 + b_hh (30 + 30 tiles)                          :110-113
+  for (int tt = w; tt < 2 * (G3 / 16); tt += TL_R) {
+    const int hh = tt >= G3 / 16, n0 = 16 * (tt - hh * (G3 / 16));
+    tail_tile<HID>(tl + (hh ? TL_B1 : TL_B0), TL_LD, hh ? t.gru_w_hh[0] : t.gru_w_ih[0], hh ? t.gru_b_hh[0] : t.gru_b_ih[0],
+                   tl + (hh ? TL_GH : TL_GI), G3, n0, l);
+  }
+  __syncthreads();
+  {  // gru cell, combined = [norm(h0') + feat_n | norm(pov) | 0]                                        :110-123
+    const Row3 hn = gru_cell(tl + TL_GI + w * G3, tl + TL_GH + w * G3, row_load(tl + TL_B1 + w * TL_LD, l), l);
+    if (valid) row_store(t.h[0] + (size_t)a * HID, l, hn);
+    const Row3 on = row_norm(hn), f = row_load(tl + TL_B0 + w * TL_LD, l);
+    Row3 c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.v[i] = on.v[i] + f.v[i];
+    float *cp = tl + TL_COMB + w * TL_LDC;
+    row_store(cp, l, c);
+    const float *op = t.obs + (size_t)a * OBS_F;
+    float pv[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = l + 64 * i;
+      float v = 0.f;
+      if (e < 5 * OBS_C) {
+        const int cell = e >> 5, ch = e & 31;
+        const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0;
+        const int dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
+        v = op[(size_t)ch * OBS_W * OBS_W + (OBS_W / 2 + dy) * OBS_W + (OBS_W / 2 + dx)];
+      } else if (e < POV) {
+        v = t.action_input[(size_t)a * ACT + (e - 5 * OBS_C)];
+      }
+      pv[i] = v;
+      s += fabsf(v);
+    }
+    s = wave_sum(s) + 1e-8f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = l + 64 * i;
+      if (e < COMB_PAD - HID) cp[HID + e] = (e < POV) ? pv[i] * (float)HID / s : 0.f;
+    }
+    row_store(tl + TL_B1 + w * TL_LD, l, row_load(t.h[1] + (size_t)a * HID, l));  // h1 takes h0's place
+  }
+  __syncthreads();
+  if (w < HID / 16) tail_tile<COMB_PAD>(tl + TL_COMB, TL_LDC, t.comb_w, t.comb_b, tl + TL_Y0, TL_LD, 16 * w, l);  // :125
+  __syncthreads();
+  row_store(tl + TL_B2 + w * TL_LD, l, row_norm(row_load(tl + TL_Y0 + w * TL_LD, l)));  // gated_n :126
+  __syncthreads();
+  for (int tt = w; tt < 2 * (G3 / 16); tt += TL_R) {  // gru1                                             :128-131
+    const int hh = tt >= G3 / 16, n0 = 16 * (tt - hh * (G3 / 16));
+    tail_tile<HID>(tl + (hh ? TL_B1 : TL_B2), TL_LD, hh ? t.gru_w_hh[1] : t.gru_w_ih[1], hh ? t.gru_b_hh[1] : t.gru_b_ih[1],
+                   tl + (hh ? TL_GH : TL_GI), G3, n0, l);
+  }
+  __syncthreads();
+  {  // out = norm(h1') + gated_n; both heads start from norm(out)
+    const Row3 hn = gru_cell(tl + TL_GI + w * G3, tl + TL_GH + w * G3, row_load(tl + TL_B1 + w * TL_LD, l), l);
+    if (valid) row_store(t.h[1] + (size_t)a * HID, l, hn);
+    const Row3 on = row_norm(hn), gn = row_load(tl + TL_B2 + w * TL_LD, l);
+    Row3 o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.v[i] = on.v[i] + gn.v[i];
+    const Row3 xn = row_norm(o);
+    row_store(tl + TL_X0 + w * TL_LD, l, xn);
+    row_store(tl + TL_X1 + w * TL_LD, l, xn);
+  }
+  __syncthreads();
+  for (int i = 0; i < 3; ++i) {  // ResB layers of the two heads                                           :41-48
+    for (int tt = w; tt < 2 * (HID / 16); tt += TL_R) {
+      const int hd = tt >= HID / 16, n0 = 16 * (tt - hd * (HID / 16));
+      tail_tile<HID>(tl + (hd ? TL_X1 : TL_X0), TL_LD, t.res_w[hd][i], t.res_b[hd][i], tl + (hd ? TL_LIN1 : TL_LIN0), TL_LD, n0, l);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hd = 0; hd < 2; ++hd) {
+      float *xp = tl + (hd ? TL_X1 : TL_X0) + w * TL_LD;
+      const Row3 y = row_load(tl + (hd ? TL_LIN1 : TL_LIN0) + w * TL_LD, l), xv = row_load(xp, l);
+      Row3 r;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) r.v[q] = fmaxf(y.v[q], 0.f) + xv.v[q];
+      row_store(xp, l, row_norm(r));
+    }
+    __syncthreads();
+  }
+  {  // p = softmax(W_p x_p + b_p) + 1e-8, v = sigmoid(W_v x_v + b_v)                                      :172-175
+    const Row3 p = row_load(tl + TL_X0 + w * TL_LD, l), v = row_load(tl + TL_X1 + w * TL_LD, l);
+    float logit[ACT];
+#pragma unroll
+    for (int k = 0; k < ACT; ++k) {
+      const Row3 wr = row_load(t.head_w[0] + k * HID, l);
+      logit[k] = wave_sum(p.v[0] * wr.v[0] + p.v[1] * wr.v[1] + p.v[2] * wr.v[2]) + t.head_b[0][k];
+    }
+    const Row3 wr = row_load(t.head_w[1], l);
+    const float val = wave_sum(v.v[0] * wr.v[0] + v.v[1] * wr.v[1] + v.v[2] * wr.v[2]) + t.head_b[1][0];
+    float mx = logit[0];
+#pragma unroll
+    for (int k = 1; k < ACT; ++k) mx = fmaxf(mx, logit[k]);
+    float e[ACT], s = 0.f;
+#pragma unroll
+    for (int k = 0; k < ACT; ++k) e[k] = expf(logit[k] - mx), s += e[k];
+    if (valid && l < ACT) {
+      float mine = e[0];
+#pragma unroll
+      for (int k = 1; k < ACT; ++k) mine = (l == k) ? e[k] : mine;
+      t.probs[(size_t)a * ACT + l] = mine / s + 1e-8f;
+    }
+    if (valid && l == 0) t.value[a] = sigmoidf_(val);
+  }
+}
+
 __global__ void k_reset_memory(float *h0, float *h1, float *action_input, const uint8_t *mask, int agents) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int a = i / HID, e = i - a * HID;
@@ -1081,6 +1277,7 @@ struct Policy {
   bool dense_conv0 = false;   // SF_POLICY_DENSE_CONV0=1: the implicit-GEMM conv0 instead (A/B, tests)
   void *conv_w3[4] = {};      // conv1, conv2: the weights split into bf16 hi / mid / lo parts for k_gemm_b3
   bool f32_conv = false;      // SF_POLICY_F32_CONV=1: conv1, conv2 on the f32 matrix pipe instead (A/B, tests)
+  bool fused_tail = true;     // SF_POLICY_FUSED_TAIL=0: the layers behind conv2 as 16 separate launches instead (A/B, tests)
   float *conv_w[4] = {}, *gru_w_ih[2] = {}, *gru_w_hh[2] = {}, *gru_b_ih[2] = {}, *gru_b_hh[2] = {};
   float *comb_w = nullptr, *comb_b = nullptr;
   float *res_w[2][3] = {}, *res_b[2][3] = {}, *head_w[2] = {}, *head_b[2] = {};  // [0] policy, [1] value
@@ -1154,23 +1351,31 @@ struct Policy {
     else if (g.M >= 16384) launch_t<4, 1, 32, MODE>(g);
     else launch_t<1, 5, 32, MODE>(g);
   }
+  // timing of one matrix launch: records the start event, returns the end event to record behind the launch
+  int time_begin(double fl, bool split, hipEvent_t *e1) {
+    *e1 = nullptr;
+    if (!timing) return SF_OK;
+    if (used_events == events.size()) {
+      hipEvent_t a, b;
+      SFP_HIP(hipEventCreate(&a));
+      SFP_HIP(hipEventCreate(&b));
+      events.emplace_back(a, b);
+      event_split.push_back(0);
+    }
+    const hipEvent_t e0 = events[used_events].first;
+    *e1 = events[used_events].second;
+    event_split[used_events] = split ? 1 : 0;
+    ++used_events;
+    (split ? flop_split : flop) += fl;
+    SFP_HIP(hipEventRecord(e0, stream));
+    return SF_OK;
+  }
   int gemm(const Gemm &g, int mode) {
     if (g.K % 32 || g.N % BN || g.M < 1) return fail(SF_ERR_ARG, "policy gemm: unsupported shape");
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timing) {
-      if (used_events == events.size()) {
-        hipEvent_t a, b;
-        SFP_HIP(hipEventCreate(&a));
-        SFP_HIP(hipEventCreate(&b));
-        events.emplace_back(a, b);
-        event_split.push_back(0);
-      }
-      e0 = events[used_events].first, e1 = events[used_events].second;
-      ++used_events;
-      const bool split = g.W3 && mode != MODE_NCHW;
-      event_split[used_events - 1] = split ? 1 : 0;
-      (split ? flop_split : flop) += 2.0 * g.M * g.N * g.K * (g.A2 ? 2 : 1);
-      SFP_HIP(hipEventRecord(e0, stream));
+    hipEvent_t e1 = nullptr;
+    {
+      const int rc = time_begin(2.0 * g.M * g.N * g.K * (g.A2 ? 2 : 1), g.W3 && mode != MODE_NCHW, &e1);
+      if (rc) return rc;
     }
     switch (mode) {
       case MODE_DENSE: launch_m<MODE_DENSE>(g); break;
@@ -1178,7 +1383,7 @@ struct Policy {
       default: launch_m<MODE_NCHW>(g); break;
     }
     SFP_HIP(hipGetLastError());
-    if (timing) SFP_HIP(hipEventRecord(e1, stream));
+    if (e1) SFP_HIP(hipEventRecord(e1, stream));
     return SF_OK;
   }
   int dense(const float *A, int lda, const float *W, const float *bias, float *C, int ldc, int M, int N, int K) {
@@ -1260,6 +1465,10 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
   {
     const char *e = getenv("SF_POLICY_F32_CONV");
     p->f32_conv = e && e[0] == '1';
+    const char *ft = getenv("SF_POLICY_FUSED_TAIL");
+    p->fused_tail = !(ft && ft[0] == '0');
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TL_LDS) != hipSuccess)
+      SFP_TRY(fail(SF_ERR_DEVICE, "k_tail needs 133 KB of LDS per workgroup"));
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_b3<MODE_NHWC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)B3_LDS) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_b3<MODE_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1329,6 +1538,25 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
   }
   if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, HID, 0, p->conv_w3[1]))) return rc;
   if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, HID, 0, p->conv_w3[2]))) return rc;
+  if (p->fused_tail) {
+    // (timed as one launch on the f32 pipe: conv3 + 4 GRU gate products + combined_processor + 6 ResB layers)
+    hipEvent_t e1 = nullptr;
+    if ((rc = p->time_begin(2.0 * agents * ((double)HID * 9 * HID + 4.0 * G3 * HID + (double)HID * COMB_PAD + 6.0 * HID * HID), false, &e1)))
+      return rc;
+    TailArgs t{};
+    t.act2 = p->act[2], t.obs = d_obs, t.conv3_w = p->conv_w[3];
+    for (int g = 0; g < 2; ++g) {
+      t.gru_w_ih[g] = p->gru_w_ih[g], t.gru_w_hh[g] = p->gru_w_hh[g], t.gru_b_ih[g] = p->gru_b_ih[g], t.gru_b_hh[g] = p->gru_b_hh[g];
+      t.h[g] = p->h[g], t.head_w[g] = p->head_w[g], t.head_b[g] = p->head_b[g];
+      for (int i = 0; i < 3; ++i) t.res_w[g][i] = p->res_w[g][i], t.res_b[g][i] = p->res_b[g][i];
+    }
+    t.comb_w = p->comb_w, t.comb_b = p->comb_b, t.action_input = p->action_input;
+    t.probs = d_probs, t.value = d_value, t.agents = agents;
+    hipLaunchKernelGGL(k_tail, dim3((unsigned)((agents + TL_R - 1) / TL_R)), dim3(TL_T), TL_LDS, st, t);
+    SFP_HIP(hipGetLastError());
+    if (e1) SFP_HIP(hipEventRecord(e1, st));
+    return SF_OK;
+  }
   if ((rc = p->conv(p->act[2], p->conv_w[3], p->feat, agents, 3, HID, 0))) return rc;
   float *const none = nullptr;
   hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->feat, p->feat_n, none, agents);               // :108
