@@ -996,8 +996,11 @@ constexpr int TL_B0 = TL_A + TL_R * TL_LDX;          // feat_n
 constexpr int TL_B1 = TL_B0 + TL_R * TL_LD;          // h0, then h1
 constexpr int TL_B2 = TL_B1 + TL_R * TL_LD;          // gated_n
 constexpr int TL_Y0 = TL_B2 + TL_R * TL_LD;          // feat, then gated
-constexpr int TL_FLOATS = TL_Y0 + TL_R * TL_LD;
-constexpr int TL_LDS = TL_FLOATS * 4;                // 135 680 bytes
+constexpr int TL_PV = TL_Y0 + TL_R * TL_LD;          // raw pov values and h1, fetched at the start
+constexpr int TL_LDP = 192;                          // a pov row: 169 values, three per lane
+constexpr int TL_H1 = TL_PV + TL_R * TL_LDP;
+constexpr int TL_FLOATS = TL_H1 + TL_R * TL_LD;
+constexpr int TL_LDS = TL_FLOATS * 4;                // 158 720 bytes
 static_assert(TL_COMB + TL_R * TL_LDC <= TL_B0 && TL_X1 + TL_R * TL_LD <= TL_B0, "region A holds its tenants");
 
 struct TailArgs {
@@ -1014,23 +1017,24 @@ struct TailArgs {
 // out[r][n0 + c] = bias[n0 + c] + sum_k in[r][k] * W[n0 + c][k] for the 16 agents r and 16 columns c of one tile
 template <int K>
 __device__ inline void tail_tile(const float *in, int ldi, const float *W, const float *bias, float *out, int ldo, int n0, int l) {
-  constexpr int STEPS = K / 16, U = (STEPS % 10 == 0) ? 10 : 11, NBATCH = STEPS / U;
-  static_assert(STEPS % U == 0, "K / 16 must split into whole batches");
+  constexpr int STEPS = K / 16, U = 8, NBATCH = (STEPS + U - 1) / U;  // weight loads in batches of 8 float4, two batches in flight
   const int row = l & 15, g = l >> 4;
   const float *ap = in + row * ldi + 4 * g;
   const float *wp = W + (size_t)(n0 + row) * K + 4 * g;
   f32x4v acc = {0.f, 0.f, 0.f, 0.f};
   f32x4 wq[2][U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) wq[0][u] = ldg4(wp + 16 * u);
+  for (int u = 0; u < U; ++u)
+    if (u < STEPS) wq[0][u] = ldg4(wp + 16 * u);
 #pragma unroll
   for (int b = 0; b < NBATCH; ++b) {
-    if (b + 1 < NBATCH) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) wq[(b + 1) & 1][u] = ldg4(wp + 16 * ((b + 1) * U + u));
-    }
+    for (int u = 0; u < U; ++u)
+      if ((b + 1) * U + u < STEPS) wq[(b + 1) & 1][u] = ldg4(wp + 16 * ((b + 1) * U + u));
+    __builtin_amdgcn_sched_barrier(0);  // (the compiler would sink every load to just in front of its MFMAs: 2 in flight)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      if (b * U + u >= STEPS) continue;
       const f32x4 a4 = *reinterpret_cast<const f32x4 *>(ap + 16 * (b * U + u));
       const f32x4 w4 = wq[b & 1][u];
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w4.x, acc, 0, 0, 0);
@@ -1057,6 +1061,26 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     for (int i = l; i < 9 * HID / 4; i += 64) dst[i] = src[i];
     row_store(tl + TL_B1 + w * TL_LD, l, row_load(t.h[0] + (size_t)a * HID, l));
   }
+  // fetched now, used after gru0: the agent's pov (5 cells x 32 channels around the centre of the observation, then the
+  // action one-hot) and its h1 — 160 scattered HBM lines, issued together with conv3's input
+  {
+    const float *op = t.obs + (size_t)a * OBS_F;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = l + 64 * i;
+      float v = 0.f;
+      if (e < 5 * OBS_C) {
+        const int cell = e >> 5, ch = e & 31;
+        const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0;
+        const int dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
+        v = op[(size_t)ch * OBS_W * OBS_W + (OBS_W / 2 + dy) * OBS_W + (OBS_W / 2 + dx)];
+      } else if (e < POV) {
+        v = t.action_input[(size_t)a * ACT + (e - 5 * OBS_C)];
+      }
+      tl[TL_PV + w * TL_LDP + e] = v;
+    }
+    row_store(tl + TL_H1 + w * TL_LD, l, row_load(t.h[1] + (size_t)a * HID, l));
+  }
   __syncthreads();
   if (w < HID / 16) tail_tile<9 * HID>(tl + TL_A, TL_LDX, t.conv3_w, nullptr, tl + TL_Y0, TL_LD, 16 * w, l);  // Modules.hpp:66-71
   __syncthreads();
@@ -1078,23 +1102,13 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     for (int i = 0; i < 3; ++i) c.v[i] = on.v[i] + f.v[i];
     float *cp = tl + TL_COMB + w * TL_LDC;
     row_store(cp, l, c);
-    const float *op = t.obs + (size_t)a * OBS_F;
     float pv[3];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int e = l + 64 * i;
-      float v = 0.f;
-      if (e < 5 * OBS_C) {
-        const int cell = e >> 5, ch = e & 31;
-        const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0;
-        const int dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
-        v = op[(size_t)ch * OBS_W * OBS_W + (OBS_W / 2 + dy) * OBS_W + (OBS_W / 2 + dx)];
-      } else if (e < POV) {
-        v = t.action_input[(size_t)a * ACT + (e - 5 * OBS_C)];
-      }
-      pv[i] = v;
-      s += fabsf(v);
+      pv[i] = tl[TL_PV + w * TL_LDP + e];
+      s += fabsf(pv[i]);
     }
     s = wave_sum(s) + 1e-8f;
 #pragma unroll
@@ -1102,7 +1116,7 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
       const int e = l + 64 * i;
       if (e < COMB_PAD - HID) cp[HID + e] = (e < POV) ? pv[i] * (float)HID / s : 0.f;
     }
-    row_store(tl + TL_B1 + w * TL_LD, l, row_load(t.h[1] + (size_t)a * HID, l));  // h1 takes h0's place
+    row_store(tl + TL_B1 + w * TL_LD, l, row_load(tl + TL_H1 + w * TL_LD, l));  // h1 takes h0's place
   }
   __syncthreads();
   if (w < HID / 16) tail_tile<COMB_PAD>(tl + TL_COMB, TL_LDC, t.comb_w, t.comb_b, tl + TL_Y0, TL_LD, 16 * w, l);  // :125
@@ -1144,29 +1158,24 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     }
     __syncthreads();
   }
-  {  // p = softmax(W_p x_p + b_p) + 1e-8, v = sigmoid(W_v x_v + b_v)                                      :172-175
-    const Row3 p = row_load(tl + TL_X0 + w * TL_LD, l), v = row_load(tl + TL_X1 + w * TL_LD, l);
-    float logit[ACT];
+  // p = softmax(W_p x_p + b_p) + 1e-8, v = sigmoid(W_v x_v + b_v)                                           :172-175
+  // (the two output layers as one MFMA tile each: weights padded with zero rows to 16 columns)
+  if (w < 2) tail_tile<HID>(tl + (w ? TL_X1 : TL_X0), TL_LD, t.head_w[w], t.head_b[w], tl + (w ? TL_LIN1 : TL_LIN0), TL_LD, 0, l);
+  __syncthreads();
+  if (valid) {
+    const float *lg = tl + TL_LIN0 + w * TL_LD;
+    float mx = lg[0];
+#pragma unroll
+    for (int k = 1; k < ACT; ++k) mx = fmaxf(mx, lg[k]);
+    float s = 0.f, mine = 0.f;
 #pragma unroll
     for (int k = 0; k < ACT; ++k) {
-      const Row3 wr = row_load(t.head_w[0] + k * HID, l);
-      logit[k] = wave_sum(p.v[0] * wr.v[0] + p.v[1] * wr.v[1] + p.v[2] * wr.v[2]) + t.head_b[0][k];
+      const float e = expf(lg[k] - mx);
+      s += e;
+      mine = (l == k) ? e : mine;
     }
-    const Row3 wr = row_load(t.head_w[1], l);
-    const float val = wave_sum(v.v[0] * wr.v[0] + v.v[1] * wr.v[1] + v.v[2] * wr.v[2]) + t.head_b[1][0];
-    float mx = logit[0];
-#pragma unroll
-    for (int k = 1; k < ACT; ++k) mx = fmaxf(mx, logit[k]);
-    float e[ACT], s = 0.f;
-#pragma unroll
-    for (int k = 0; k < ACT; ++k) e[k] = expf(logit[k] - mx), s += e[k];
-    if (valid && l < ACT) {
-      float mine = e[0];
-#pragma unroll
-      for (int k = 1; k < ACT; ++k) mine = (l == k) ? e[k] : mine;
-      t.probs[(size_t)a * ACT + l] = mine / s + 1e-8f;
-    }
-    if (valid && l == 0) t.value[a] = sigmoidf_(val);
+    if (l < ACT) t.probs[(size_t)a * ACT + l] = mine / s + 1e-8f;
+    if (l == 0) t.value[a] = sigmoidf_(tl[TL_LIN1 + w * TL_LD]);
   }
 }
 
@@ -1281,6 +1290,7 @@ struct Policy {
   float *conv_w[4] = {}, *gru_w_ih[2] = {}, *gru_w_hh[2] = {}, *gru_b_ih[2] = {}, *gru_b_hh[2] = {};
   float *comb_w = nullptr, *comb_b = nullptr;
   float *res_w[2][3] = {}, *res_b[2][3] = {}, *head_w[2] = {}, *head_b[2] = {};  // [0] policy, [1] value
+  float *head_w16[2] = {}, *head_b16[2] = {};  // the same padded with zero rows to one 16-column MFMA tile (k_tail)
   // per-agent state and scratch
   float *h[2] = {}, *action_input = nullptr;
   float *act[3] = {};  // NHWC conv outputs 15x15, 7x7, 3x3
@@ -1468,7 +1478,7 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
     const char *ft = getenv("SF_POLICY_FUSED_TAIL");
     p->fused_tail = !(ft && ft[0] == '0');
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TL_LDS) != hipSuccess)
-      SFP_TRY(fail(SF_ERR_DEVICE, "k_tail needs 133 KB of LDS per workgroup"));
+      SFP_TRY(fail(SF_ERR_DEVICE, "k_tail needs 155 KB of LDS per workgroup"));
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_b3<MODE_NHWC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)B3_LDS) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_b3<MODE_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1498,6 +1508,14 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
   SFP_TRY(p->upload(&p->head_b[0], w->policy_b, ACT));
   SFP_TRY(p->upload(&p->head_w[1], w->value_w, HID));
   SFP_TRY(p->upload(&p->head_b[1], w->value_b, 1));
+  for (int g = 0; g < 2; ++g) {
+    const int rows = g ? 1 : ACT;
+    std::vector<float> wpad((size_t)16 * HID, 0.f), bpad(16, 0.f);
+    std::memcpy(wpad.data(), g ? w->value_w : w->policy_w, (size_t)rows * HID * sizeof(float));
+    std::memcpy(bpad.data(), g ? w->value_b : w->policy_b, (size_t)rows * sizeof(float));
+    SFP_TRY(p->upload(&p->head_w16[g], wpad.data(), wpad.size()));
+    SFP_TRY(p->upload(&p->head_b16[g], bpad.data(), bpad.size()));
+  }
   const size_t B = (size_t)max_agents;
   SFP_TRY(p->dalloc(&p->h[0], B * HID));
   SFP_TRY(p->dalloc(&p->h[1], B * HID));
@@ -1547,7 +1565,7 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
     t.act2 = p->act[2], t.obs = d_obs, t.conv3_w = p->conv_w[3];
     for (int g = 0; g < 2; ++g) {
       t.gru_w_ih[g] = p->gru_w_ih[g], t.gru_w_hh[g] = p->gru_w_hh[g], t.gru_b_ih[g] = p->gru_b_ih[g], t.gru_b_hh[g] = p->gru_b_hh[g];
-      t.h[g] = p->h[g], t.head_w[g] = p->head_w[g], t.head_b[g] = p->head_b[g];
+      t.h[g] = p->h[g], t.head_w[g] = p->head_w16[g], t.head_b[g] = p->head_b16[g];
       for (int i = 0; i < 3; ++i) t.res_w[g][i] = p->res_w[g][i], t.res_b[g][i] = p->res_b[g][i];
     }
     t.comb_w = p->comb_w, t.comb_b = p->comb_b, t.action_input = p->action_input;
