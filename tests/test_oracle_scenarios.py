@@ -267,3 +267,81 @@ def test_chest_pickup(impl):
     assert (h.stamina, h.hp, h.mindamage) == (1000000 + 20, 1000 + 50, 100 + 10)
     assert s[1].flags[cell] == 0 and s[1].hdr.chests == 0
     assert (s[2].humans[0].stamina, s[2].humans[0].hp) == (1000020, 1050)  # claimed once
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two players: whose bullet, whose team, whose credit (human_damage G:611-634, Character::hit CH:242-246)
+# ---------------------------------------------------------------------------------------------------------------------
+def corridor_workload(teams, seed=1700000000):
+    """Battle start (random cells and facings, G:1846-1858) in a one-row corridor, so that the three players stand in line."""
+    rows = cols = 16
+    grid = [["#"] * cols for _ in range(rows)]
+    for c in range(1, 8):
+        grid[1][c] = "."
+    m = "".join("".join(row) for row in grid).encode()
+    cfg = config.make_config(1, rows, cols, H=4, Z=2, B=8, P=4, mode=abi.MODE_BATTLE, n_agents=3, teams=teams, auto_reset=0)
+    w = config.Workload("corridor", cfg, m, [-1] * (rows * cols))
+    w.seed = seed
+    return w
+
+
+def _duel(impl, friendly):
+    # where the players start does not depend on their teams (the placement draws come first): look, then pick the teams
+    probe = impl(corridor_workload([1, 2, 3]))
+    probe.reset(*probe.w.seeds(base_tb=probe.w.seed))
+    h = probe.dump(0).humans
+    cols = [h[i].c for i in range(3)]
+    assert all(h[i].alive and h[i].r == 1 for i in range(3)) and len(set(cols)) == 3
+    others = sorted((abs(cols[i] - cols[0]), i) for i in (1, 2))
+    tgt = others[0][1]                       # the nearer one: nobody stands between it and player 0
+    third = 3 - tgt
+    teams = [1, 0, 0]
+    teams[tgt], teams[third] = (1, 2) if friendly else (2, 3)
+    w = corridor_workload(teams)
+    sim = impl(w)
+    sim.reset(*w.seeds(base_tb=w.seed))
+    d0 = sim.dump(0)
+    assert [d0.humans[i].c for i in range(3)] == cols
+    right = cols[tgt] > cols[0]
+    want_way = 2 if right else 4             # way - 1 indexes wdx/wdy = {1,0,-1,0}/{0,1,0,-1} (G:742-758): 2 = right, 4 = left
+    script = "q" * ((want_way - d0.humans[0].way) % 4)             # turn_l: 4 -> 1, else way + 1 (CH:745-759)
+    script += ("d" if right else "a") * (abs(cols[tgt] - cols[0]) - 1)  # walk up to the cell next to the target
+    script += "m"                                                  # AK_47, as in test_gun_shot_flight_and_wall
+    snaps = []
+    for ch in script + "xxxx":
+        sim.step(np.array([ord(ch), ord("+"), ord("+")], dtype=np.uint8))
+        snaps.append(sim.dump(0))
+    assert len(script) + 4 < 19  # before the first periodic spawn (frame 20) could put anyone else into the corridor
+    return sim, snaps[-4:], tgt, third
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_shooting_a_rival_dead(impl):
+    # Each shot is put on the neighbour's cell (G:796-819) and lands in the same step's hit_human: Hp -= 300,
+    # mindamage += -105 (CH:242-246; the bullet of test_gun_shot_flight_and_wall).  The shooter is of another team, so its
+    # own damage / effect counters grow by the bullet's (G:615-618), and when the fourth shot takes Hp to -200:
+    # mh = false, ++teams_kills, loot += 100, and because the owner is the player itself loot += 900, ++kills (G:623-627);
+    # increase_kills() on the owner (G:628-629).  A player of a third team is still alive: no end of the match.
+    sim, s, tgt, third = _duel(impl, friendly=False)
+    for n, d in enumerate(s, start=1):
+        v, me = d.humans[tgt], d.humans[0]
+        assert (v.hp, v.mindamage) == (1000 - 300 * n, 100 - 105 * n)
+        assert (me.damage, me.effect, me.stamina, me.mindamage) == (300 * n, -105 * n, 1000000 - 50 * n, 100)
+        assert sum(b.alive for b in d.bullets) == 0
+        assert v.alive == (1 if n < 4 else 0)
+        assert (me.kills, d.hdr.kills, d.hdr.teams_kills, d.hdr.loot) == ((0, 0, 0, 0) if n < 4 else (1, 1, 1, 1000))
+    assert s[-1].humans[third].alive == 1 and (s[-1].hdr.done, s[-1].hdr.outcome) == (0, abi.RUNNING)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_shooting_a_team_mate_dead(impl):
+    # The same four shots at a player of the shooter's own team: the victim is hit all the same (CH:242-246 knows no
+    # teams), but none of it is credited — no damage / effect (G:615), no teams_kills / loot / kills (the dead player is of
+    # hum[ind]'s team, G:623), no increase_kills (G:628).
+    sim, s, tgt, third = _duel(impl, friendly=True)
+    for n, d in enumerate(s, start=1):
+        v, me = d.humans[tgt], d.humans[0]
+        assert (v.hp, v.mindamage, v.alive) == (1000 - 300 * n, 100 - 105 * n, 1 if n < 4 else 0)
+        assert (me.damage, me.effect, me.kills, me.stamina) == (0, 0, 0, 1000000 - 50 * n)
+        assert (d.hdr.kills, d.hdr.teams_kills, d.hdr.loot) == (0, 0, 0)
+    assert s[-1].humans[third].alive == 1 and (s[-1].hdr.done, s[-1].hdr.outcome) == (0, abi.RUNNING)
