@@ -191,6 +191,16 @@ int sf_observe_device(sf_env *env, float *d_out);
  * another pointer, or one after a plain observe call on it writes everything.  The buffer ends up bit-identical
  * to what the plain call would have written. */
 int sf_observe_device_delta(sf_env *env, float *d_out);
+/* The same observation as the list of its non-zero floats, for a consumer on the device that can take it in that form
+ * (sf_policy_forward_sparse: the bot network's first convolution works on the non-zeros anyway): nothing dense is
+ * written at all.  Per (arena, agent) i: d_counts[i] entries, in the dense buffer's own order (channel, then row, then
+ * column), d_keys[i * cap + e] = channel * 9 | row << 9 | column << 14 and d_vals[i * cap + e] the float the dense
+ * call would have written there, bit for bit; d_pov[i * 160 ..] = the 5 x 32 floats around the window's centre that
+ * AgentModel::forward reads directly (Modules.hpp:114-121: cells (-1,0) (0,-1) (0,0) (0,1) (1,0), channel fastest).
+ * d_counts[i] > cap (the list was cut) or == 0xffffffff (a window more crowded than the kernel's record table) means:
+ * take the dense call for this step.  An observation of the BASELINE configurations has ~250 non-zeros. */
+#define SF_OBS_POV_FLOATS 160
+int sf_observe_sparse_device(sf_env *env, uint32_t *d_keys, float *d_vals, uint32_t *d_counts, float *d_pov, int32_t cap);
 
 /* Per (arena, agent) 8 x int32: kills, teams_kills, loot, damage, effect, Hp, frames, outcome
  * (gameplay.hpp:461,588-593,625-629; Character.hpp:294).  Latched at episode end. */

@@ -70,6 +70,16 @@ int sf_policy_reset_memory_n(sf_policy *p, const uint8_t *d_mask, int32_t agents
  * (sigmoid), and advances every agent's h_state. */
 int sf_policy_forward(sf_policy *p, const float *d_obs, int32_t agents, float *d_probs, float *d_value);
 
+/* sf_policy_forward on the observation in list form (sf_observe_sparse_device: d_keys / d_vals [agents][cap],
+ * d_counts [agents], d_pov [agents][160]): the first convolution takes the non-zeros as they come instead of scanning a
+ * dense 123 KB buffer per agent for them, and the five centre cells come from d_pov.  Same results as the dense call,
+ * bit for bit (same values applied in the same order).  An agent whose count exceeds cap or 2048, or is the
+ * 0xffffffff marker, is evaluated on an empty observation and counted: sf_policy_sparse_overflows() returns (and
+ * clears) that count — non-zero means the caller should have taken the dense pair of calls for that step. */
+int sf_policy_forward_sparse(sf_policy *p, const uint32_t *d_keys, const float *d_vals, const uint32_t *d_counts,
+                             const float *d_pov, int32_t cap, int32_t agents, float *d_probs, float *d_value);
+int sf_policy_sparse_overflows(sf_policy *p, int32_t *count);
+
 /* The tail of Agent::predict() + Agent::update() (Agent.hpp:200-222): v[0] = 0.5, v[i>0] *= 0.5/(1-v[0]+1e-5),
  * draw from discrete_distribution(v) (greedy != 0: arg-max of v instead), store the one-hot as the agent's
  * action_input (update_actions) and write command char action_string[a] to d_cmd[agent] (gameplay::bot,

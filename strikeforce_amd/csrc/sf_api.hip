@@ -93,7 +93,18 @@ static __device__ __forceinline__ int obs_class_of(uint32_t fl) {
 // mode 0: plain.  mode 1: plain + record which floats are non-zero in nzprev.  mode 2 (sf_observe_device_delta): the
 // buffer still holds what the previous call left, nzprev says which floats of it are non-zero: only 16-byte pieces
 // with an old or a new non-zero are written.
-__global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out, uint32_t *nzprev, int mode) {
+// mode 3 (sf_observe_sparse_device): no dense buffer at all — the non-zero floats leave as a list in the dense buffer's
+// scan order (key = channel * 9 | y << 9 | x << 14: the form k_conv0_sparse's list has, value), `cap` entries per agent at
+// most (counts[] says how many there were: more than cap, or 0xffffffff for a window too crowded for the records, tells the
+// caller to take the dense path), plus the 160 values around the window's centre that the network reads directly.
+struct ObsSparse {
+  uint32_t *keys;
+  float *vals;
+  uint32_t *counts;
+  float *pov;
+  int cap;
+};
+__global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out, uint32_t *nzprev, int mode, ObsSparse sp) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ent[];  // [13][H] humans, [3][Z] zombies, [4][B] bullets
   __shared__ float rec[OBS_REC_MAX][SF_OBS_CHANNELS];
   __shared__ uint32_t occ[OBS_W2];
@@ -124,6 +135,11 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   const uint32_t hf = gptr(p.hum)[((size_t)HW_FLAGS * p.A + a) * p.H + g];
   const uint32_t center = gptr(p.hum)[((size_t)HW_POS * p.A + a) * p.H + g];
   SF_GLOBAL uint32_t *old = nzprev ? gptr(nzprev) + (size_t)blockIdx.x * OBS_W2 : nullptr;
+  if (mode == 3 && (hf & (HF_ALIVE | HF_CTRL)) != (HF_ALIVE | HF_CTRL)) {  // no observer: an empty list
+    if (tid == 0) gptr(sp.counts)[blockIdx.x] = 0u;
+    if (tid < 5 * SF_OBS_CHANNELS) gptr(sp.pov)[(size_t)blockIdx.x * (5 * SF_OBS_CHANNELS) + tid] = 0.f;
+    return;
+  }
   if ((hf & (HF_ALIVE | HF_CTRL)) != (HF_ALIVE | HF_CTRL)) {  // no observer: all zero (uniform over the workgroup)
     for (int i = tid; i < SF_OBS_FLOATS / 4; i += OBS_THREADS)
       if (mode != 2 || ((old[(4u * (uint32_t)i) >> 5] >> ((4u * (uint32_t)i) & 31u)) & 15u))
@@ -263,6 +279,53 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
     for (uint32_t i = (uint32_t)tid; i < n; i += OBS_THREADS) (&rec[0][0])[list_idx[i]] = obs_map(list_val[i]);
   }
   lds_barrier();
+  // ---- pass 4, sparse form -----------------------------------------------------------------------------------
+  if (mode == 3) {
+    __shared__ uint32_t wave_tot[OBS_THREADS / 64];
+    // thread t owns bitmap words 4 t .. 4 t + 3 (bits = dense indices in ascending order); an exclusive scan of the
+    // threads' non-zero counts gives every entry its place in scan order
+    uint32_t wv[4], cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int w = 4 * tid + j;
+      wv[j] = w < OBS_W2 ? nzmap[w] : 0u;
+      cnt += (uint32_t)__builtin_popcount(wv[j]);
+    }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+      if ((tid & 63) >= o) incl += up;
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    lds_barrier();
+    uint32_t pos = incl - cnt, total = 0;
+#pragma unroll
+    for (int q = 0; q < OBS_THREADS / 64; ++q) {
+      if (q < (tid >> 6)) pos += wave_tot[q];
+      total += wave_tot[q];
+    }
+    SF_GLOBAL uint32_t *kd = gptr(sp.keys) + (size_t)blockIdx.x * (size_t)sp.cap;
+    SF_GLOBAL float *vd = gptr(sp.vals) + (size_t)blockIdx.x * (size_t)sp.cap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      for (uint32_t m = wv[j]; m; m &= m - 1u) {
+        const uint32_t idx = 32u * (uint32_t)(4 * tid + j) + (uint32_t)__builtin_ctz(m);
+        const uint32_t k = idx / (uint32_t)OBS_W2, w = idx - k * (uint32_t)OBS_W2;
+        const uint32_t y = w / (uint32_t)SF_OBS_WINDOW, x = w - y * (uint32_t)SF_OBS_WINDOW;
+        if (pos < (uint32_t)sp.cap) kd[pos] = (k * 9u) | (y << 9) | (x << 14), vd[pos] = rec[slot[w]][k];
+        ++pos;
+      }
+    if (tid == 0) gptr(sp.counts)[blockIdx.x] = spill_n ? 0xffffffffu : total;
+    if (tid < 5 * SF_OBS_CHANNELS) {  // the network's pov: cells (-1,0) (0,-1) (0,0) (0,1) (1,0) around the centre, Modules.hpp:114-121
+      const int cell = tid >> 5, ch = tid & 31;
+      const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0, dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
+      const uint32_t w = (uint32_t)((SF_OBS_WINDOW / 2 + dy) * SF_OBS_WINDOW + (SF_OBS_WINDOW / 2 + dx));
+      const uint32_t bit = (uint32_t)ch * (uint32_t)OBS_W2 + w;
+      gptr(sp.pov)[(size_t)blockIdx.x * (5 * SF_OBS_CHANNELS) + tid] = ((nzmap[bit >> 5] >> (bit & 31u)) & 1u) ? rec[slot[w]][ch] : 0.f;
+    }
+    return;
+  }
   // ---- pass 4 ----------------------------------------------------------------------------------------------
   const bool delta = mode == 2 && spill_n == 0u;  // (a window crowded beyond the records is written in full)
   if (delta) {  // the old map next to the new one in LDS (over wdmg): one coalesced read instead of one per piece
@@ -441,7 +504,16 @@ struct HipRT {
     hipLaunchKernelGGL(k_observe, dim3((unsigned)(p.A * p.n_agents)), dim3(OBS_THREADS),
                        (size_t)(HW_WORDS * p.H + ZW_WORDS * p.Z + BW_WORDS * p.B) * sizeof(uint32_t) + sizeof(int32_t) * 12 +
                            sizeof(Derived) * (size_t)(p.npc_block + 1),
-                       stream, p, out, nzprev, mode);
+                       stream, p, out, nzprev, mode, ObsSparse{});
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+  }
+  int launch_observe_sparse(const Params &p, uint32_t *keys, float *vals, uint32_t *counts, float *pov, int cap) {
+    SF_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_observe, dim3((unsigned)(p.A * p.n_agents)), dim3(OBS_THREADS),
+                       (size_t)(HW_WORDS * p.H + ZW_WORDS * p.Z + BW_WORDS * p.B) * sizeof(uint32_t) + sizeof(int32_t) * 12 +
+                           sizeof(Derived) * (size_t)(p.npc_block + 1),
+                       stream, p, (float *)nullptr, (uint32_t *)nullptr, 3, ObsSparse{keys, vals, counts, pov, cap});
     SF_HIP(hipGetLastError());
     return SF_OK;
   }
@@ -579,6 +651,10 @@ int sf_observe_device_delta(sf_env *env, float *d_out) {
 int sf_observe_device(sf_env *env, float *d_out) {
   SF_ENV(env);
   return env->e.observe_device(d_out);
+}
+int sf_observe_sparse_device(sf_env *env, uint32_t *d_keys, float *d_vals, uint32_t *d_counts, float *d_pov, int32_t cap) {
+  SF_ENV(env);
+  return env->e.observe_sparse_device(d_keys, d_vals, d_counts, d_pov, cap);
 }
 int sf_results(sf_env *env, int32_t *out_host) {
   SF_ENV(env);

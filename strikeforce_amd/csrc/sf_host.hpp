@@ -373,6 +373,12 @@ struct Env {
     if (d_out == delta_ptr) delta_ptr = nullptr;  // a plain write: the non-zero map no longer describes this buffer
     return rt.launch_observe(p, NB, d_out, nullptr, 0);
   }
+  int observe_sparse_device(uint32_t *d_keys, float *d_vals, uint32_t *d_counts, float *d_pov, int cap) {
+    if (!d_keys || !d_vals || !d_counts || !d_pov) return fail(SF_ERR_ARG, "null buffer");
+    if (cap < 1) return fail(SF_ERR_ARG, "sf_observe_sparse_device: cap must be positive");
+    if (!was_reset) return fail(SF_ERR_STATE, "sf_observe before sf_reset");
+    return rt.launch_observe_sparse(p, d_keys, d_vals, d_counts, d_pov, cap);
+  }
   int observe_device_delta(float *d_out) {
     if (!d_out) return fail(SF_ERR_ARG, "null observation buffer");
     if (!was_reset) return fail(SF_ERR_STATE, "sf_observe before sf_reset");

@@ -649,7 +649,17 @@ constexpr int C0_T = 1024, C0_WAVES = C0_T / 64;
 constexpr int C0_LCAP = 2048;
 constexpr size_t C0_LDS = (size_t)C0_ACC * 4 + (size_t)C0_LCAP * 8 + 4 * (2 * 16 * C0_WAVES + 4);
 
-__global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const float *wt, float *act0, int agents) {
+// LIST: the non-zeros arrive as a list (sf_observe_sparse_device: same keys, same order as the scan below builds), so the
+// 123 KB scan of the dense observation is gone; `obs` is unused.
+struct C0List {
+  const uint32_t *keys;
+  const float *vals;
+  const uint32_t *counts;
+  int cap;
+  uint32_t *overflows;  // bumped once per agent whose list did not fit (it is then evaluated on an empty list)
+};
+template <bool LIST>
+__global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const float *wt, float *act0, int agents, C0List li) {
   extern __shared__ __attribute__((aligned(16))) float c0_lds[];
   float *acc = c0_lds;
   float *lval = acc + C0_ACC;
@@ -723,6 +733,43 @@ __global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const f
     }
   };
 
+  if (LIST) {
+    // entries of the next agent wait in registers (two per thread cover C0_LCAP) while this one's are applied
+    constexpr int EPT = C0_LCAP / C0_T;
+    uint32_t pk[EPT], pn = 0;
+    float pvv[EPT];
+    auto fetch = [&](int b) {
+      pn = li.counts[b];
+      if (pn > (uint32_t)C0_LCAP || pn > (uint32_t)li.cap) {
+        pn = 0u;
+        if (t == 0) atomicAdd(li.overflows, 1u);
+      }
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const uint32_t e = (uint32_t)(k * C0_T + t);
+        pk[k] = 0u, pvv[k] = 0.f;
+        if (e < pn) pk[k] = li.keys[(size_t)b * li.cap + e], pvv[k] = li.vals[(size_t)b * li.cap + e];
+      }
+    };
+    if ((int)blockIdx.x < agents) fetch((int)blockIdx.x);
+    for (int b = (int)blockIdx.x; b < agents; b += (int)gridDim.x) {
+      for (int i = t; i < C0_ACC / 4; i += C0_T) reinterpret_cast<f32x4 *>(acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const uint32_t n = pn;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const uint32_t e = (uint32_t)(k * C0_T + t);
+        if (e < n) lkey[e] = pk[k], lval[e] = pvv[k];
+      }
+      __syncthreads();
+      if (b + (int)gridDim.x < agents) fetch(b + (int)gridDim.x);
+      process(n);
+      __syncthreads();
+      f32x4 *dst = reinterpret_cast<f32x4 *>(act0 + (size_t)b * C0_ACC);
+      for (int i = t; i < C0_ACC / 4; i += C0_T) dst[i] = reinterpret_cast<const f32x4 *>(acc)[i];
+      __syncthreads();  // the tile has been read out before the next agent zeroes it
+    }
+    return;
+  }
   // The workgroup is persistent (one per CU: the output tile fills its LDS) and walks agents b, b + gridDim.x, ...:
   // the next agent's observation is requested as soon as this one's has been scanned, so its latency passes under
   // this agent's list processing and write-back, and the write-back's stores drain under the next agent's scan.
@@ -1004,7 +1051,7 @@ constexpr int TL_LDS = TL_FLOATS * 4;                // 158 720 bytes
 static_assert(TL_COMB + TL_R * TL_LDC <= TL_B0 && TL_X1 + TL_R * TL_LD <= TL_B0, "region A holds its tenants");
 
 struct TailArgs {
-  const float *act2, *obs, *conv3_w;
+  const float *act2, *obs, *pov, *conv3_w;  // pov: the 160 centre values as a dense row per agent, or null (gather them from obs)
   const float *gru_w_ih[2], *gru_w_hh[2], *gru_b_ih[2], *gru_b_hh[2];
   const float *comb_w, *comb_b;
   const float *res_w[2][3], *res_b[2][3], *head_w[2], *head_b[2];
@@ -1070,10 +1117,14 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
       const int e = l + 64 * i;
       float v = 0.f;
       if (e < 5 * OBS_C) {
-        const int cell = e >> 5, ch = e & 31;
-        const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0;
-        const int dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
-        v = op[(size_t)ch * OBS_W * OBS_W + (OBS_W / 2 + dy) * OBS_W + (OBS_W / 2 + dx)];
+        if (t.pov) {
+          v = t.pov[(size_t)a * (5 * OBS_C) + e];
+        } else {
+          const int cell = e >> 5, ch = e & 31;
+          const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0;
+          const int dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
+          v = op[(size_t)ch * OBS_W * OBS_W + (OBS_W / 2 + dy) * OBS_W + (OBS_W / 2 + dx)];
+        }
       } else if (e < POV) {
         v = t.action_input[(size_t)a * ACT + (e - 5 * OBS_C)];
       }
@@ -1286,6 +1337,7 @@ struct Policy {
   bool dense_conv0 = false;   // SF_POLICY_DENSE_CONV0=1: the implicit-GEMM conv0 instead (A/B, tests)
   void *conv_w3[4] = {};      // conv1, conv2: the weights split into bf16 hi / mid / lo parts for k_gemm_b3
   bool f32_conv = false;      // SF_POLICY_F32_CONV=1: conv1, conv2 on the f32 matrix pipe instead (A/B, tests)
+  uint32_t *d_overflows = nullptr;  // sf_policy_forward_sparse: agents whose list did not fit since the last query
   bool fused_tail = true;     // SF_POLICY_FUSED_TAIL=0: the layers behind conv2 as 16 separate launches instead (A/B, tests)
   float *conv_w[4] = {}, *gru_w_ih[2] = {}, *gru_w_hh[2] = {}, *gru_b_ih[2] = {}, *gru_b_hh[2] = {};
   float *comb_w = nullptr, *comb_b = nullptr;
@@ -1452,7 +1504,9 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
     SFP_TRY(p->upload(&p->conv0_wt, tr.data(), tr.size()));
     const char *e = getenv("SF_POLICY_DENSE_CONV0");
     p->dense_conv0 = e && e[0] == '1';
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv0_sparse), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv0_sparse<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)C0_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv0_sparse<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)C0_LDS) != hipSuccess)
       SFP_TRY(fail(SF_ERR_DEVICE, "k_conv0_sparse needs 157 KB of LDS per workgroup"));
   }
@@ -1536,23 +1590,34 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
   SFP_TRY(p->dalloc(&p->lin[0], B * HID));
   SFP_TRY(p->dalloc(&p->lin[1], B * HID));
   SFP_TRY(p->dalloc(&p->part, (size_t)p->sk_blocks * 2 * 128 * BN));
+  {
+    float *f = nullptr;
+    SFP_TRY(p->dalloc(&f, 1));
+    p->d_overflows = reinterpret_cast<uint32_t *>(f);
+    SFP_HIP(hipMemset(p->d_overflows, 0, sizeof(uint32_t)));
+  }
 #undef SFP_TRY
   *out = reinterpret_cast<sf_policy *>(p);
   return sf_policy_reset_memory(*out, nullptr);
 }
 
-static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, float *d_value) {
+static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, float *d_value, const C0List *li = nullptr,
+                   const float *d_pov = nullptr) {
   int rc = check_agents(p, agents);
   if (rc) return rc;
-  if (!d_obs || !d_probs || !d_value) return fail(SF_ERR_ARG, "null buffer");
+  if ((!d_obs && !li) || !d_probs || !d_value) return fail(SF_ERR_ARG, "null buffer");
+  if (li && !p->fused_tail) return fail(SF_ERR_STATE, "sf_policy_forward_sparse needs the fused tail (SF_POLICY_FUSED_TAIL=0 is set)");
   SFP_HIP(hipSetDevice(p->device));
   const dim3 rg((unsigned)((agents + 3) / 4)), rb(256);
   hipStream_t st = p->stream;
   // GameCNN                                                                    Modules.hpp:66-71
-  if (p->dense_conv0) {
+  const dim3 c0_grid((unsigned)(agents < p->sk_blocks / 2 ? agents : p->sk_blocks / 2));
+  if (li) {
+    hipLaunchKernelGGL(k_conv0_sparse<true>, c0_grid, dim3(C0_T), C0_LDS, st, (const float *)nullptr, p->conv0_wt, p->act[0], agents, *li);
+  } else if (p->dense_conv0) {
     if ((rc = p->conv(d_obs, p->conv_w[0], p->act[0], agents, 31, OBS_C, 1))) return rc;
   } else {
-    hipLaunchKernelGGL(k_conv0_sparse, dim3((unsigned)(agents < p->sk_blocks / 2 ? agents : p->sk_blocks / 2)), dim3(C0_T), C0_LDS, st, d_obs, p->conv0_wt, p->act[0], agents);
+    hipLaunchKernelGGL(k_conv0_sparse<false>, c0_grid, dim3(C0_T), C0_LDS, st, d_obs, p->conv0_wt, p->act[0], agents, C0List{});
   }
   if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, HID, 0, p->conv_w3[1]))) return rc;
   if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, HID, 0, p->conv_w3[2]))) return rc;
@@ -1562,7 +1627,7 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
     if ((rc = p->time_begin(2.0 * agents * ((double)HID * 9 * HID + 4.0 * G3 * HID + (double)HID * COMB_PAD + 6.0 * HID * HID), false, &e1)))
       return rc;
     TailArgs t{};
-    t.act2 = p->act[2], t.obs = d_obs, t.conv3_w = p->conv_w[3];
+    t.act2 = p->act[2], t.obs = d_obs, t.pov = d_pov, t.conv3_w = p->conv_w[3];
     for (int g = 0; g < 2; ++g) {
       t.gru_w_ih[g] = p->gru_w_ih[g], t.gru_w_hh[g] = p->gru_w_hh[g], t.gru_b_ih[g] = p->gru_b_ih[g], t.gru_b_hh[g] = p->gru_b_hh[g];
       t.h[g] = p->h[g], t.head_w[g] = p->head_w16[g], t.head_b[g] = p->head_b16[g];
@@ -1639,6 +1704,27 @@ int sf_policy_reset_memory(sf_policy *pp, const uint8_t *d_mask) {
 
 int sf_policy_forward(sf_policy *pp, const float *d_obs, int32_t agents, float *d_probs, float *d_value) {
   return sfp::forward(reinterpret_cast<Policy *>(pp), d_obs, agents, d_probs, d_value);
+}
+
+int sf_policy_forward_sparse(sf_policy *pp, const uint32_t *d_keys, const float *d_vals, const uint32_t *d_counts,
+                             const float *d_pov, int32_t cap, int32_t agents, float *d_probs, float *d_value) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
+  if (!d_keys || !d_vals || !d_counts || !d_pov || cap < 1) return sfp::fail(SF_ERR_ARG, "null buffer or cap < 1");
+  const sfp::C0List li{d_keys, d_vals, d_counts, cap, p->d_overflows};
+  return sfp::forward(p, nullptr, agents, d_probs, d_value, &li, d_pov);
+}
+
+int sf_policy_sparse_overflows(sf_policy *pp, int32_t *count) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p || !count) return sfp::fail(SF_ERR_ARG, "null argument");
+  SFP_HIP(hipSetDevice(p->device));
+  SFP_HIP(hipStreamSynchronize(p->stream));
+  uint32_t n = 0;
+  SFP_HIP(hipMemcpy(&n, p->d_overflows, sizeof(n), hipMemcpyDeviceToHost));
+  SFP_HIP(hipMemset(p->d_overflows, 0, sizeof(n)));
+  *count = (int32_t)n;
+  return SF_OK;
 }
 
 int sf_policy_act(sf_policy *pp, const float *d_probs, int32_t agents, const char *action_string, uint64_t seed,

@@ -45,6 +45,7 @@ def load_library():
         L.sf_step_device.argtypes = [vp, vp, C.c_int32]
         L.sf_observe_device.argtypes = [vp, vp]
         L.sf_observe_device_delta.argtypes = [vp, vp]
+        L.sf_observe_sparse_device.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
         L.sf_results_device.argtypes = [vp, vp]
         L.sf_done_device.argtypes = [vp, vp]
         L.sf_set_stream.argtypes = [vp, vp]
@@ -58,7 +59,7 @@ def load_library():
             getattr(L, n).restype = C.c_int
         L.sf_config_defaults.argtypes = [C.POINTER(abi.Config)]
         L.sf_config_defaults.restype = None
-        for n in ("sf_step_device", "sf_observe_device", "sf_observe_device_delta", "sf_results_device", "sf_done_device", "sf_set_stream", "sf_synchronize",
+        for n in ("sf_step_device", "sf_observe_device", "sf_observe_device_delta", "sf_observe_sparse_device", "sf_results_device", "sf_done_device", "sf_set_stream", "sf_synchronize",
                   "sf_kernel_time", "sf_abi_version"):
             getattr(L, n).restype = C.c_int
         L.sf_last_error.restype = C.c_char_p
@@ -68,7 +69,7 @@ def load_library():
 
 # every symbol include/strikeforce.h declares
 EXPORTS = ["sf_create", "sf_destroy", "sf_config_defaults", "sf_reset", "sf_step", "sf_step_device", "sf_observe",
-           "sf_observe_device", "sf_observe_device_delta", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
+           "sf_observe_device", "sf_observe_device_delta", "sf_observe_sparse_device", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
            "sf_set_stream", "sf_synchronize", "sf_kernel_time", "sf_last_error", "sf_abi_version",
            "sf_comm_unique_id", "sf_comm_init", "sf_results_allgather", "sf_comm_wait"]
 
@@ -135,6 +136,12 @@ class ArenaBatch:
     def observe_device_delta(self, d_out_ptr):
         """observe_device for ONE persistent, caller-untouched buffer per env: only what changed is written."""
         self._ck(self.L.sf_observe_device_delta(self.h, C.c_void_p(d_out_ptr)), "sf_observe_device_delta")
+
+    def observe_sparse_device(self, d_keys_ptr, d_vals_ptr, d_counts_ptr, d_pov_ptr, cap):
+        """The observation as the list of its non-zero floats ([agents][cap] keys and values, [agents] counts,
+        [agents][160] centre values): what PolicyBatch.forward_sparse consumes."""
+        self._ck(self.L.sf_observe_sparse_device(self.h, C.c_void_p(d_keys_ptr), C.c_void_p(d_vals_ptr), C.c_void_p(d_counts_ptr),
+                                                 C.c_void_p(d_pov_ptr), int(cap)), "sf_observe_sparse_device")
 
     def observe_device(self, d_out_ptr):
         self._ck(self.L.sf_observe_device(self.h, C.c_void_p(d_out_ptr)), "sf_observe_device")

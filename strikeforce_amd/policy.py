@@ -112,6 +112,8 @@ def _bind(L):
     L.sf_policy_reset_memory_n.argtypes = [vp, vp, C.c_int32]
     L.sf_policy_reset_memory_n.restype = C.c_int
     L.sf_policy_forward.argtypes = [vp, vp, C.c_int32, vp, vp]
+    L.sf_policy_forward_sparse.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp]
+    L.sf_policy_sparse_overflows.argtypes = [vp, C.POINTER(C.c_int32)]
     L.sf_policy_act.argtypes = [vp, vp, C.c_int32, C.c_char_p, C.c_uint64, C.c_int32, vp, vp]
     L.sf_policy_get_memory.argtypes = [vp, C.c_int32, _FP, _FP]
     L.sf_policy_set_memory.argtypes = [vp, C.c_int32, _FP, _FP]
@@ -128,7 +130,8 @@ def _bind(L):
 
 
 # every symbol include/strikeforce_policy.h declares
-EXPORTS = ["sf_policy_create", "sf_policy_destroy", "sf_policy_reset_memory", "sf_policy_reset_memory_n", "sf_policy_forward", "sf_policy_act",
+EXPORTS = ["sf_policy_create", "sf_policy_destroy", "sf_policy_reset_memory", "sf_policy_reset_memory_n", "sf_policy_forward", "sf_policy_forward_sparse",
+           "sf_policy_sparse_overflows", "sf_policy_act",
            "sf_policy_get_memory", "sf_policy_set_memory", "sf_policy_set_stream", "sf_policy_synchronize",
            "sf_policy_kernel_time", "sf_policy_kernel_time_ex", "sf_policy_gemm", "sf_policy_gemm_split", "sf_policy_abi_version"]
 
@@ -204,6 +207,18 @@ class PolicyBatch:
     def forward(self, d_obs_ptr, agents, d_probs_ptr, d_value_ptr):
         self._ck(self.L.sf_policy_forward(self.h, C.c_void_p(d_obs_ptr), int(agents), C.c_void_p(d_probs_ptr),
                                           C.c_void_p(d_value_ptr)), "sf_policy_forward")
+
+    def forward_sparse(self, d_keys_ptr, d_vals_ptr, d_counts_ptr, d_pov_ptr, cap, agents, d_probs_ptr, d_value_ptr):
+        """forward() on ArenaBatch.observe_sparse_device's lists: same results, no dense observation in between."""
+        self._ck(self.L.sf_policy_forward_sparse(self.h, C.c_void_p(d_keys_ptr), C.c_void_p(d_vals_ptr), C.c_void_p(d_counts_ptr),
+                                                 C.c_void_p(d_pov_ptr), int(cap), int(agents), C.c_void_p(d_probs_ptr),
+                                                 C.c_void_p(d_value_ptr)), "sf_policy_forward_sparse")
+
+    def sparse_overflows(self):
+        """Agents evaluated on an empty observation since the last call because their list did not fit (synchronises)."""
+        n = C.c_int32()
+        self._ck(self.L.sf_policy_sparse_overflows(self.h, C.byref(n)), "sf_policy_sparse_overflows")
+        return n.value
 
     def act(self, d_probs_ptr, agents, d_cmd_ptr, seed=0, greedy=False, d_action_ptr=None,
             action_string=ACTION_STRING):

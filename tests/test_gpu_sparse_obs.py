@@ -1,0 +1,95 @@
+"""The observation handed from the simulator to the bot network as the list of its non-zero floats
+(sf_observe_sparse_device -> sf_policy_forward_sparse, include/strikeforce*.h): the list is exactly the dense observation's
+non-zeros in the dense buffer's order, and the network's outputs are bit-identical to the dense pair of calls."""
+import numpy as np
+import pytest
+import torch
+
+from oracle_lib import Oracle
+from strikeforce_amd import config, env, policy
+
+pytestmark = pytest.mark.gpu
+CAP = 2048
+
+
+def _bufs(B):
+    return (torch.zeros((B, CAP), dtype=torch.int32, device="cuda"), torch.zeros((B, CAP), dtype=torch.float32, device="cuda"),
+            torch.zeros(B, dtype=torch.int32, device="cuda"), torch.zeros((B, 160), dtype=torch.float32, device="cuda"))
+
+
+def _advance(w, g, steps):
+    cmds, _ = config.bench_commands(w.cfg.arenas, w.cfg.n_agents, steps)
+    d = torch.from_numpy(np.ascontiguousarray(cmds)).cuda()
+    torch.cuda.synchronize()
+    g.step_device(d.data_ptr(), steps)
+    g.synchronize()
+
+
+@pytest.mark.parametrize("which", ["C2", "C3", "C5", "KITS"])
+def test_the_list_is_the_dense_observation(which):
+    w = config.baseline_workload(which, arenas=6)
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    B = w.cfg.arenas * w.cfg.n_agents
+    _advance(w, g, 150)  # zombies, bullets, chests and corpses in view
+    d_obs = torch.zeros((B, 32, 31, 31), dtype=torch.float32, device="cuda")
+    keys, vals, counts, pov = _bufs(B)
+    g.observe_device(d_obs.data_ptr())
+    g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP)
+    g.synchronize()
+    obs = d_obs.cpu().numpy().reshape(B, -1)
+    k, v, n, pv = keys.cpu().numpy().view(np.uint32), vals.cpu().numpy(), counts.cpu().numpy().view(np.uint32), pov.cpu().numpy()
+    assert n.max() <= CAP and n.max() > 0
+    for a in range(B):
+        nz = np.flatnonzero(obs[a])           # ascending dense index = channel, row, column
+        assert n[a] == len(nz)
+        ch, r = np.divmod(nz, 961)
+        y, x = np.divmod(r, 31)
+        assert np.array_equal(k[a, :n[a]], (ch * 9) | (y << 9) | (x << 14))
+        assert np.array_equal(v[a, :n[a]].view(np.uint32), obs[a][nz].view(np.uint32))
+    o4 = obs.reshape(B, 32, 31, 31)
+    cells = [(14, 15), (15, 14), (15, 15), (15, 16), (16, 15)]  # Modules.hpp:114-121
+    want = np.stack([o4[:, :, yy, xx] for yy, xx in cells], axis=1).reshape(B, 160)
+    assert np.array_equal(pv.view(np.uint32), want.view(np.uint32))
+
+
+def test_sparse_and_dense_forward_are_bit_identical():
+    w = config.baseline_workload("C3", arenas=40)
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    B = w.cfg.arenas * w.cfg.n_agents
+    params = policy.init_parameters(seed=4)
+    dense, sparse = policy.PolicyBatch(params, B), policy.PolicyBatch(params, B)
+    d_obs = torch.zeros((B, 32, 31, 31), dtype=torch.float32, device="cuda")
+    keys, vals, counts, pov = _bufs(B)
+    out = [(torch.zeros((B, 9), device="cuda"), torch.zeros(B, device="cuda")) for _ in range(2)]
+    for _ in range(4):  # recurrent steps, the world moving in between
+        _advance(w, g, 25)
+        g.observe_device(d_obs.data_ptr())
+        g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP)
+        dense.forward(d_obs.data_ptr(), B, out[0][0].data_ptr(), out[0][1].data_ptr())
+        sparse.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP, B, out[1][0].data_ptr(),
+                              out[1][1].data_ptr())
+        dense.synchronize(), sparse.synchronize()
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert sparse.sparse_overflows() == 0
+    assert float(out[0][0].std()) > 0
+
+
+def test_a_list_that_does_not_fit_is_counted():
+    w = config.baseline_workload("C2", arenas=8)
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    B = w.cfg.arenas * w.cfg.n_agents
+    pb = policy.PolicyBatch(policy.init_parameters(0), B)
+    cap = 16  # far too small: every agent sees more than 16 non-zero floats
+    keys = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    vals = torch.zeros((B, cap), dtype=torch.float32, device="cuda")
+    counts, pov = torch.zeros(B, dtype=torch.int32, device="cuda"), torch.zeros((B, 160), device="cuda")
+    probs, value = torch.zeros((B, 9), device="cuda"), torch.zeros(B, device="cuda")
+    g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), cap)
+    g.synchronize()
+    assert int(counts.min()) > cap  # the true counts are reported, the lists cut
+    pb.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), cap, B, probs.data_ptr(), value.data_ptr())
+    assert pb.sparse_overflows() == B
+    assert pb.sparse_overflows() == 0  # cleared by the query

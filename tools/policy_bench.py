@@ -48,3 +48,29 @@ g.synchronize()
 pb.synchronize()
 wall = (time.perf_counter() - t0) / iters
 print(json.dumps({"closed_loop_ms_per_step": wall * 1e3, "closed_loop_agent_steps_per_s": B / wall}))
+# the same with the observation handed over as the list of its non-zeros (no dense buffer written or read)
+CAP = 2048
+keys = torch.zeros((B, CAP), dtype=torch.int32, device="cuda")
+vals = torch.zeros((B, CAP), dtype=torch.float32, device="cuda")
+counts = torch.zeros(B, dtype=torch.int32, device="cuda")
+pov = torch.zeros((B, 160), dtype=torch.float32, device="cuda")
+for _ in range(2):
+    g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP)
+    pb.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP, B, d_probs.data_ptr(), d_value.data_ptr())
+pb.synchronize()
+t0 = time.perf_counter()
+for _ in range(iters):
+    pb.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP, B, d_probs.data_ptr(), d_value.data_ptr())
+pb.synchronize()
+fwd = (time.perf_counter() - t0) / iters
+t0 = time.perf_counter()
+for _ in range(iters):
+    g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP)
+    pb.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP, B, d_probs.data_ptr(), d_value.data_ptr())
+    pb.act(d_probs.data_ptr(), B, d_cmd.data_ptr(), seed=1)
+    g.step_device(d_cmd.data_ptr(), 1)
+g.synchronize()
+pb.synchronize()
+wall = (time.perf_counter() - t0) / iters
+print(json.dumps({"sparse_forward_ms": fwd * 1e3, "sparse_closed_loop_ms_per_step": wall * 1e3,
+                  "sparse_closed_loop_agent_steps_per_s": B / wall, "overflows": pb.sparse_overflows()}))
