@@ -337,10 +337,19 @@ def main():
         d_new = torch.zeros(agents, dtype=torch.uint8, device="cuda")
         pol_n = 10
 
+        SP_CAP = 2048  # list entries per agent (an observation of the BASELINE configurations has ~250 non-zero floats)
+        d_keys = torch.zeros((agents, SP_CAP), dtype=torch.int32, device="cuda")
+        d_vals = torch.zeros((agents, SP_CAP), dtype=torch.float32, device="cuda")
+        d_counts = torch.zeros(agents, dtype=torch.int32, device="cuda")
+        d_pov = torch.zeros((agents, 160), dtype=torch.float32, device="cuda")
+
         def closed_loop(n):
             for _ in range(n):
-                g.observe_device_delta(d_obs.data_ptr())
-                pb.forward(d_obs.data_ptr(), agents, d_probs.data_ptr(), d_value.data_ptr())
+                # the observation goes to the network as the list of its non-zeros (bit-identical results to the dense
+                # sf_observe_device + sf_policy_forward pair, tests/test_gpu_sparse_obs.py)
+                g.observe_sparse_device(d_keys.data_ptr(), d_vals.data_ptr(), d_counts.data_ptr(), d_pov.data_ptr(), SP_CAP)
+                pb.forward_sparse(d_keys.data_ptr(), d_vals.data_ptr(), d_counts.data_ptr(), d_pov.data_ptr(), SP_CAP, agents,
+                                  d_probs.data_ptr(), d_value.data_ptr())
                 pb.act(d_probs.data_ptr(), agents, d_pcmd.data_ptr(), seed=rank)
                 g.step_device(d_pcmd.data_ptr(), 1)
                 g.done_device(d_new.data_ptr())      # agents whose game restarted get a fresh memory,
@@ -355,7 +364,8 @@ def main():
         pe[1].record()
         torch.cuda.synchronize()
         (f_ms, f_flop, f_n), (s_ms, s_flop, s_n) = pb.kernel_time_by_pipe(False)
-        pol = {"loop_ms": pe[0].elapsed_time(pe[1]) / pol_n, "gemm_ms": (f_ms + s_ms) / pol_n, "gemm_flop": (f_flop + s_flop) / pol_n,
+        sp_over = pb.sparse_overflows()
+        pol = {"sparse_overflows": sp_over, "loop_ms": pe[0].elapsed_time(pe[1]) / pol_n, "gemm_ms": (f_ms + s_ms) / pol_n, "gemm_flop": (f_flop + s_flop) / pol_n,
                "gemm_launches": (f_n + s_n) // pol_n, "split_ms": s_ms / pol_n, "split_flop": s_flop / pol_n,
                "split_launches": s_n // pol_n, "f32_ms": f_ms / pol_n, "f32_flop": f_flop / pol_n, "steps": pol_n, "agents": agents}
         pb.close()
@@ -427,9 +437,10 @@ def main():
             bf16_tf = 6.0 * pol["split_flop"] / (pol["split_ms"] / 1e3) / 1e12 if pol["split_ms"] > 0 else 0.0
             f32_tf = pol["f32_flop"] / (pol["f32_ms"] / 1e3) / 1e12 if pol["f32_ms"] > 0 else 0.0
             out["policy"] = {
-                "what": "per rank: observe -> bot-0.5 network (f32 results, random-init weights; conv0 on the observation's "
-                        "non-zeros, conv1/conv2 as bf16 hi/mid/lo split products on the bf16 MFMA, conv3 and the dense layers "
-                        "on the f32 MFMA) -> sample -> K=1 step, all on device, %d steps" % pol["steps"],
+                "what": "per rank: observe (as the list of non-zero floats) -> bot-0.5 network (f32 results, random-init weights; "
+                        "conv0 on those non-zeros, conv1/conv2 as bf16 hi/mid/lo split products on the bf16 MFMA, everything behind "
+                        "conv2 in one kernel on the f32 MFMA) -> sample -> K=1 step -> memory reset of restarted games, all on "
+                        "device, %d steps; agents whose list overflowed: %d" % (pol["steps"], pol["sparse_overflows"]),
                 "agent_steps_per_s": world * pol["agents"] / (pol["loop_ms"] / 1e3), "ms_per_step": pol["loop_ms"],
                 "roofline": {"bound": "mfma", "achieved": bf16_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": bf16_tf / MFMA_BF16_PEAK_TFLOPS,
