@@ -286,10 +286,10 @@ def main():
 
     # the interactive loop an RL learner runs: one launch per step (K = 1) + the observation of every agent
     obs_n = 0 if args.no_interactive else 40
-    loop_ms = obs_ms = k1_ms = host_ms = loop_delta_ms = 0.0
+    loop_ms = obs_ms = k1_ms = host_ms = loop_delta_ms = loop_sparse_ms = 0.0
     if obs_n:
         d_obs = torch.empty(args.arenas * cfg.n_agents * 30752, dtype=torch.float32, device="cuda")
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
         g.observe_device(d_obs.data_ptr())
         torch.cuda.synchronize()
         ev[0].record()
@@ -310,7 +310,21 @@ def main():
             g.step_device(d_cmds.data_ptr() + (s % total) * stride, 1)
             g.observe_device_delta(d_obs.data_ptr())
         ev[5].record()
+        # the same loop with the observation as the list of its non-zero floats (what sf_policy_forward_sparse consumes)
+        n_ag = args.arenas * cfg.n_agents
+        s_keys = torch.zeros((n_ag, 2048), dtype=torch.int32, device="cuda")
+        s_vals = torch.zeros((n_ag, 2048), dtype=torch.float32, device="cuda")
+        s_cnt = torch.zeros(n_ag, dtype=torch.int32, device="cuda")
+        s_pov = torch.zeros((n_ag, 160), dtype=torch.float32, device="cuda")
+        g.observe_sparse_device(s_keys.data_ptr(), s_vals.data_ptr(), s_cnt.data_ptr(), s_pov.data_ptr(), 2048)
+        ev[6].record()
+        for s in range(obs_n):
+            g.step_device(d_cmds.data_ptr() + (s % total) * stride, 1)
+            g.observe_sparse_device(s_keys.data_ptr(), s_vals.data_ptr(), s_cnt.data_ptr(), s_pov.data_ptr(), 2048)
+        ev[7].record()
         torch.cuda.synchronize()
+        loop_sparse_ms = ev[6].elapsed_time(ev[7]) / obs_n
+        del s_keys, s_vals, s_cnt, s_pov
         loop_ms = ev[0].elapsed_time(ev[1]) / obs_n
         obs_ms = ev[1].elapsed_time(ev[2]) / obs_n
         k1_ms = ev[2].elapsed_time(ev[3]) / obs_n
@@ -426,6 +440,10 @@ def main():
                                             "floats written; buffer bit-identical to the plain call's)",
                                     "env_steps_per_s": world * args.arenas / (loop_delta_ms / 1e3),
                                     "ms_per_step": loop_delta_ms},
+              "sparse_observation": {"what": "same loop with sf_observe_sparse_device (the non-zero floats as a list, the form "
+                                             "sf_policy_forward_sparse takes; no dense buffer)",
+                                     "env_steps_per_s": world * args.arenas / (loop_sparse_ms / 1e3),
+                                     "ms_per_step": loop_sparse_ms},
             "sf_step_host_cmd_ms": host_ms,
               "k_observe_roofline": {"bound": "hbm", "achieved": obs_bytes / (obs_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": obs_bytes / (obs_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
