@@ -307,15 +307,36 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
     }
     SF_GLOBAL uint32_t *kd = gptr(sp.keys) + (size_t)blockIdx.x * (size_t)sp.cap;
     SF_GLOBAL float *vd = gptr(sp.vals) + (size_t)blockIdx.x * (size_t)sp.cap;
+    auto emit = [&](uint32_t e, uint32_t idx) {  // entry e of the list: dense index -> key, value
+      const uint32_t k = idx / (uint32_t)OBS_W2, w = idx - k * (uint32_t)OBS_W2;
+      const uint32_t y = w / (uint32_t)SF_OBS_WINDOW, x = w - y * (uint32_t)SF_OBS_WINDOW;
+      if (e < (uint32_t)sp.cap) kd[e] = (k * 9u) | (y << 9) | (x << 14), vd[e] = rec[slot[w]][k];
+    };
+    // The non-zeros cluster (a channel that marks every wall cell fills whole bitmap words), so a thread that turned its
+    // own bits into entries would make the others wait for the fullest words (13 k of the kernel's 42 k cycles).  The
+    // threads only drop their bits' dense indices into an LDS list (occ[] and wdmg[] are dead by now), and the entries
+    // are then built and stored round-robin: equal work, coalesced stores.
+    constexpr uint32_t STAGED = 2u * (uint32_t)OBS_W2;
+    if (total <= STAGED) {
+      uint32_t *stage0 = occ, *stage1 = reinterpret_cast<uint32_t *>(wdmg);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      for (uint32_t m = wv[j]; m; m &= m - 1u) {
-        const uint32_t idx = 32u * (uint32_t)(4 * tid + j) + (uint32_t)__builtin_ctz(m);
-        const uint32_t k = idx / (uint32_t)OBS_W2, w = idx - k * (uint32_t)OBS_W2;
-        const uint32_t y = w / (uint32_t)SF_OBS_WINDOW, x = w - y * (uint32_t)SF_OBS_WINDOW;
-        if (pos < (uint32_t)sp.cap) kd[pos] = (k * 9u) | (y << 9) | (x << 14), vd[pos] = rec[slot[w]][k];
-        ++pos;
-      }
+      for (int j = 0; j < 4; ++j)
+        for (uint32_t m = wv[j]; m; m &= m - 1u) {
+          const uint32_t idx = 32u * (uint32_t)(4 * tid + j) + (uint32_t)__builtin_ctz(m);
+          (pos < (uint32_t)OBS_W2 ? stage0[pos] : stage1[pos - (uint32_t)OBS_W2]) = idx;
+          ++pos;
+        }
+      lds_barrier();
+      for (uint32_t e = (uint32_t)tid; e < total; e += OBS_THREADS)
+        emit(e, e < (uint32_t)OBS_W2 ? stage0[e] : stage1[e - (uint32_t)OBS_W2]);
+    } else {  // more non-zeros than the staging area holds (never an observation of the BASELINE configurations)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        for (uint32_t m = wv[j]; m; m &= m - 1u) {
+          emit(pos, 32u * (uint32_t)(4 * tid + j) + (uint32_t)__builtin_ctz(m));
+          ++pos;
+        }
+    }
     if (tid == 0) gptr(sp.counts)[blockIdx.x] = spill_n ? 0xffffffffu : total;
     if (tid < 5 * SF_OBS_CHANNELS) {  // the network's pov: cells (-1,0) (0,-1) (0,0) (0,1) (1,0) around the centre, Modules.hpp:114-121
       const int cell = tid >> 5, ch = tid & 31;
