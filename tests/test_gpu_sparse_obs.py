@@ -93,3 +93,35 @@ def test_a_list_that_does_not_fit_is_counted():
     pb.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), cap, B, probs.data_ptr(), value.data_ptr())
     assert pb.sparse_overflows() == B
     assert pb.sparse_overflows() == 0  # cleared by the query
+
+
+def test_crowded_windows_are_marked_not_truncated():
+    """MAXCAP (64 humans, 64 zombies, 256 bullet slots on 48 x 48): windows with more occupied cells than the kernel has
+    records take the dense call's slow path; the list form must say so (count 0xffffffff) instead of handing over a partial
+    list, and every other agent's list must still equal its dense observation."""
+    w = config.baseline_workload("MAXCAP", arenas=4)
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    B = w.cfg.arenas * w.cfg.n_agents
+    marked = 0
+    for _ in range(6):
+        _advance(w, g, 40)
+        d_obs = torch.zeros((B, 32, 31, 31), dtype=torch.float32, device="cuda")
+        keys, vals, counts, pov = _bufs(B)
+        g.observe_device(d_obs.data_ptr())
+        g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP)
+        g.synchronize()
+        obs = d_obs.cpu().numpy().reshape(B, -1)
+        k, v, n = keys.cpu().numpy().view(np.uint32), vals.cpu().numpy(), counts.cpu().numpy().view(np.uint32)
+        for a in range(B):
+            nz = np.flatnonzero(obs[a])
+            if n[a] == 0xFFFFFFFF:
+                marked += 1
+                continue
+            assert n[a] == len(nz)
+            m = min(len(nz), CAP)
+            ch, r = np.divmod(nz[:m], 961)
+            y, x = np.divmod(r, 31)
+            assert np.array_equal(k[a, :m], (ch * 9) | (y << 9) | (x << 14))
+            assert np.array_equal(v[a, :m].view(np.uint32), obs[a][nz[:m]].view(np.uint32))
+    print("agents marked as crowded:", marked)
