@@ -1,5 +1,5 @@
-"""Hand-derived known answers from the reference's formulas, checked on the oracle and on the device core
-(wave emulator).  Each expectation cites the reference lines it was derived from
+"""Hand-derived known answers from the reference's formulas, checked on the oracle, on the device core run on the wave
+emulator and (-m gpu) on the device itself through the C-ABI.  Each expectation cites the reference lines it was derived from
 (G = gameplay.hpp, CH = Character.hpp, IT = Item.hpp, files under /root/reference/StrikeForce-client).
 
 The player is sealed into a 3x5 room (rows 1-3, cols 1-5) of an otherwise solid map, so the periodic random spawns
@@ -42,7 +42,13 @@ def quiet(d):
     return (sum(z.alive for z in d.zombies) == 0 and sum(h.alive for h in d.humans[1:]) == 0 and d.hdr.chests == 0)
 
 
-IMPLS = [Oracle, Emu]
+def Device(w):
+    """The HIP path through the C-ABI (same call surface as Oracle / Emu): only under `-m gpu`."""
+    from strikeforce_amd import env
+    return env.ArenaBatch(w)
+
+
+IMPLS = [pytest.param(Oracle, id="oracle"), pytest.param(Emu, id="emu"), pytest.param(Device, id="device", marks=pytest.mark.gpu)]
 
 
 @pytest.mark.parametrize("impl", IMPLS)
