@@ -10,6 +10,15 @@ from oracle_lib import Oracle, diff_dumps
 from strikeforce_amd import abi, config
 
 
+def Device(w):
+    """The HIP path through the C-ABI: only under `-m gpu`."""
+    from strikeforce_amd import env
+    return env.ArenaBatch(w)
+
+
+IMPLS = [pytest.param(Oracle, id="oracle"), pytest.param(Emu, id="emu"), pytest.param(Device, id="device", marks=pytest.mark.gpu)]
+
+
 def _fresh(impl):
     w = config.baseline_workload("KITS", arenas=2)
     sim = impl(w)
@@ -17,7 +26,7 @@ def _fresh(impl):
     return w, sim
 
 
-@pytest.mark.parametrize("impl", [Oracle, Emu], ids=["oracle", "emu"])
+@pytest.mark.parametrize("impl", IMPLS)
 def test_every_player_is_built_from_its_own_record(impl):
     _, sim = _fresh(impl)
     h = sim.dump(0).humans
@@ -34,7 +43,7 @@ def test_every_player_is_built_from_its_own_record(impl):
     assert all(x.profile == 0 for x in h[:6])
 
 
-@pytest.mark.parametrize("impl", [Oracle, Emu], ids=["oracle", "emu"])
+@pytest.mark.parametrize("impl", IMPLS)
 def test_a_shot_carries_the_shooters_own_weapon_level(impl):
     """Weapon 4 (w4.txt: damage 150, effect -55, range 100) at level L is upgraded L times by Human::build
     (Character.hpp:680-681, Weapon::upgrade Item.hpp:105-111: +50 / -50 per level).  shot_it (Character.hpp:399-408):
