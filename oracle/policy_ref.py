@@ -12,9 +12,11 @@ Two forms of the same arithmetic:
   * ``forward_batched`` — the same forward for B independent agents at once (every reduction is per agent), used as
     the fp32 reference the HIP kernels are compared with.  tests/test_policy_ref.py checks it against ``AgentModel``.
 
-Pin status: libtorch is not in this image, so the reference's own model cannot be run here; the restatement uses the
-same torch operators (conv2d, GRU, linear, softmax, sigmoid) that libtorch dispatches to, and the reference has no
-tests or golden vectors for its network.  Parity for f-4 is therefore "HIP vs this restatement", tolerance in the tests.
+Pin status: PINNED on the reference itself.  Modules.hpp:26-180 compiles unedited against the libtorch inside the torch
+wheel (oracle/ref_modules.py -> oracle/_ref/libsf_refmodules.so); tests/test_ref_modules.py holds ``AgentModel`` to the
+reference's AgentModel bit for bit (probabilities, value, both recurrent states, over recurrent steps with
+update_actions and a reset_memory, four parameter sets) and ``forward_batched`` to it within 1e-6 relative;
+tests/golden/policy_vectors.json holds the reference's own outputs, which the HIP path reproduces (-m gpu).
 """
 import numpy as np
 import torch

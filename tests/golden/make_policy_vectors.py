@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/policy_vectors.json from the PyTorch f32 restatement of the reference's bot network
-(oracle/policy_ref.py): for seeded parameters and the oracle simulator's own observations of two agents over three
-recurrent steps, the probabilities, value and a checksum of the recurrent state.  These are regression vectors of the
-restatement (libtorch, hence the reference's own model, cannot be run in this image: DESIGN.md §10).
+"""Generates tests/golden/policy_vectors.json from the REFERENCE's bot network: oracle/_ref/libsf_refmodules.so =
+bots/bot-0.5/Modules.hpp:26-180 compiled unedited against the libtorch inside the torch wheel (oracle/ref_modules.py).
+For seeded parameters and the oracle simulator's own observations of two agents over four recurrent steps (one
+reference AgentModel per agent, update_actions with the arg-max in between): the probabilities, value and a checksum of
+the recurrent state as AgentModel::forward returned them.  Needs the reference checkout (build container only); the
+vectors travel.  `run_restatement()` is the same trajectory through oracle/policy_ref.py (tests/test_policy_ref.py
+holds it to the committed vectors on machines without the reference build).
 
     python tests/golden/make_policy_vectors.py
 """
@@ -21,7 +24,7 @@ import policy_ref  # noqa: E402
 from oracle_lib import Oracle  # noqa: E402
 from strikeforce_amd import config, policy  # noqa: E402
 
-PARAM_SEED, ARENAS, STEPS, SIM_STEPS_BETWEEN = 21, 2, 3, 25
+PARAM_SEED, ARENAS, STEPS, SIM_STEPS_BETWEEN = 21, 2, 4, 25
 
 
 def trajectory():
@@ -37,7 +40,43 @@ def trajectory():
     return out
 
 
+def _record(probs, value, h, act, obs):
+    return {"probs": [[float(x) for x in r] for r in probs], "value": [float(x) for x in value],
+            "h_abs_sum": [float(np.abs(h[g]).sum()) for g in range(2)], "action_fed_back": [int(x) for x in act],
+            "obs_nonzero": int((obs != 0).sum())}
+
+
+def _header(generator):
+    return {"_generator": generator, "param_seed": PARAM_SEED, "workload": "C1", "arenas": ARENAS,
+            "sim_steps_between": SIM_STEPS_BETWEEN}
+
+
 def run():
+    """The reference's AgentModel itself (one per agent)."""
+    import refmodules
+    if refmodules.lib() is None:
+        raise SystemExit("oracle/_ref/libsf_refmodules.so is not built: run python oracle/ref_modules.py on a machine "
+                         "with the reference checkout")
+    params = policy.init_parameters(seed=PARAM_SEED)
+    models = [refmodules.RefAgentModel(params) for _ in range(ARENAS)]
+    steps = []
+    for obs in trajectory():
+        outs = [m.forward(obs[b]) for b, m in enumerate(models)]
+        probs = np.stack([o[0] for o in outs])
+        value = np.array([o[1] for o in outs], dtype=np.float32)
+        h = np.stack([o[2] for o in outs], axis=1)  # [2][B][160]
+        act = probs.argmax(axis=1)
+        for b, m in enumerate(models):
+            m.update_actions(int(act[b]))
+        steps.append(_record(probs, value, h, act, obs))
+    out = _header("tests/golden/make_policy_vectors.py run(): oracle/_ref/libsf_refmodules.so = the reference's "
+                  "bots/bot-0.5/Modules.hpp:26-180 compiled unedited (oracle/ref_modules.py), libtorch f32 on the CPU")
+    out["steps"] = steps
+    return out
+
+
+def run_restatement():
+    """The same trajectory through oracle/policy_ref.forward_batched."""
     params = policy.init_parameters(seed=PARAM_SEED)
     h = np.zeros((2, ARENAS, 160), dtype=np.float32)
     a = np.eye(9, dtype=np.float32)[[0] * ARENAS]
@@ -46,12 +85,10 @@ def run():
         probs, value, h = policy_ref.forward_batched(params, obs, h, a)
         act = probs.argmax(axis=1)
         a = np.eye(9, dtype=np.float32)[act]
-        steps.append({"probs": [[float(x) for x in r] for r in probs], "value": [float(x) for x in value],
-                      "h_abs_sum": [float(np.abs(h[g]).sum()) for g in range(2)], "action_fed_back": [int(x) for x in act],
-                      "obs_nonzero": int((obs != 0).sum())})
-    return {"_generator": "tests/golden/make_policy_vectors.py (oracle/policy_ref.py, torch f32 on the CPU)",
-            "param_seed": PARAM_SEED, "workload": "C1", "arenas": ARENAS, "sim_steps_between": SIM_STEPS_BETWEEN,
-            "steps": steps}
+        steps.append(_record(probs, value, h, act, obs))
+    out = _header("tests/golden/make_policy_vectors.py run_restatement(): oracle/policy_ref.py")
+    out["steps"] = steps
+    return out
 
 
 if __name__ == "__main__":

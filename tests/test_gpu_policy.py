@@ -266,10 +266,13 @@ def test_split_and_f32_convolutions_agree():
 
 
 def test_hip_path_reproduces_the_committed_vectors():
-    """tests/golden/policy_vectors.json (made by the torch restatement on the CPU): the GPU simulator's observations of
-    the same seeded run through the HIP network give the committed probabilities, values and state checksums."""
+    """tests/golden/policy_vectors.json = outputs of the REFERENCE's AgentModel (bots/bot-0.5/Modules.hpp:26-180
+    compiled unedited, oracle/ref_modules.py; generator tests/golden/make_policy_vectors.py): the GPU simulator's
+    observations of the same seeded run through the HIP network give the committed probabilities, values and state
+    checksums."""
     import json
     want = json.load(open(os.path.join(ROOT, "tests", "golden", "policy_vectors.json")))
+    assert "libsf_refmodules" in want["_generator"]
     A = want["arenas"]
     w = config.baseline_workload(want["workload"], arenas=A)
     g = env.ArenaBatch(w)

@@ -97,12 +97,13 @@ def test_policy_rejects_bad_parameters():
 
 
 def test_restatement_reproduces_the_committed_vectors():
-    """tests/golden/policy_vectors.json is regenerated bit-for-bit up to the f32 round-off of another torch build."""
+    """tests/golden/policy_vectors.json holds the REFERENCE network's outputs (oracle/_ref/libsf_refmodules.so, see its
+    generator); the batched restatement reproduces them up to the f32 round-off of its batched reductions."""
     import json
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import make_policy_vectors
     want = json.load(open(os.path.join(ROOT, "tests", "golden", "policy_vectors.json")))
-    got = make_policy_vectors.run()
+    got = make_policy_vectors.run_restatement()
     assert [s["action_fed_back"] for s in got["steps"]] == [s["action_fed_back"] for s in want["steps"]]
     assert [s["obs_nonzero"] for s in got["steps"]] == [s["obs_nonzero"] for s in want["steps"]]
     for g, w in zip(got["steps"], want["steps"]):
