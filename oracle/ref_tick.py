@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""ref_tick.py — TEST INFRASTRUCTURE: build oracle/_ref/sf_ref_tick, the reference's own tick path, head-less.
+
+    python oracle/ref_tick.py [--ref /root/reference] [--quiet] [--manifest]
+
+What cannot be had in this image is SFML, i.e. GraphicPrinter.hpp and its global `printer` (basic.hpp:41).  Everything
+else on the tick path is plain C++ that compiles as it stands: the whole of random.hpp, Item.hpp, Character.hpp and
+gameplay.hpp except the member functions that draw, read the keyboard or run the menus.  This recipe therefore copies
+the six files below into a temporary directory with the line ranges listed in OMIT **blanked** (replaced by empty lines,
+so that line numbers in the copy are the reference's own), and compiles oracle/ref_tick_main.cpp (ours) against the
+copies.  Every kept line is the reference's, unedited; no stand-in is written for any omitted header, function or
+object — what is omitted is simply not there, and nothing kept calls it (the compiler checks that).  Every omitted range
+is a whole declaration or member function and carries its reason below; anchor texts on the first and last line of
+each range make a reference whose lines have moved fail loudly.  The temporary directory is deleted; the binary lands
+in oracle/_ref/ (git-ignored).  Without a checkout nothing is built (exit code 0).
+
+The one class the reference leaves to the user is `Agent` (random.hpp:25 -> selected_agent.hpp:25 picks a bot's
+Agent.hpp; bots/bot-0/Agent.hpp:27-37 is the minimal form): ref_tick_main.cpp supplies a scripted one, which is the
+plug-in contract, not a stand-in.  What ref_tick_main.cpp restates from the omitted play() is the ORDER of its calls
+(gameplay.hpp:1441-1471, fifteen lines) and get_my_action's two lines that fetch the player's command
+(gameplay.hpp:955-958); check_end (gameplay.hpp:1102-1229: screens and key waits around four comparisons) stays out,
+so SURVEY §8 row a19 remains pinned by hand-derived scenarios only.
+
+Pins (tests/test_ref_tick.py): rows a4-a18 and a20 — Backpack/Human, gen_human, node/showit, the slot allocators, the
+three spawns, zombie_action, portal_damage, update_tmp, hit_human/hit_zombie, update_bull, human_action / get_command /
+human_rnpc_bot, obey, teleport, claim_chest, setup/load_data (Solo, Timer, Squad), describe + gameplay::bot — on the
+reference's native world (gameplay.hpp:37: 3 floors x 30 x 100, its caps of 9000 never reached).
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CLIENT = "StrikeForce-client"
+OUT = os.path.join(HERE, "_ref", "sf_ref_tick")
+
+# file -> [(first, last, text on the first line, text on the last line, reason)]; lines are 1-based, inclusive
+OMIT = {
+    "basic.hpp": [
+        (41, 41, '#include "GraphicPrinter.hpp"', '#include "GraphicPrinter.hpp"', "SFML (<SFML/Graphics.hpp>)"),
+        (47, 50, "void usleep(int x){", "}", "sf::sleep"),
+        (241, 259, "std::string head(bool ingame = false, bool dont = false){", "}", "printer.cls()"),
+    ],
+    "macros.hpp": [],
+    "random.hpp": [
+        (25, 25, '#include "selected_agent.hpp"', '#include "selected_agent.hpp"',
+         "the Agent plug-in slot (bot-0.5's Agent needs curl + a key press at construction, Agent.hpp:66-71); "
+         "ref_tick_main.cpp supplies the Agent class"),
+    ],
+    "Item.hpp": [(25, 25, '#include "random.hpp"', '#include "random.hpp"', "local include: the copies are included in order by ref_tick_main.cpp")],
+    "Character.hpp": [
+        (25, 25, '#include "Item.hpp"', '#include "Item.hpp"', "local include"),
+        (168, 222, "void show(int money, bool b = false, bool ingame = false) const{", "}", "Backpack::show: head(), printer, getch"),
+        (346, 349, "void show_backpack(bool b = false, bool ingame = false) const{", "}", "calls Backpack::show"),
+    ],
+    "gameplay.hpp": [
+        (25, 25, '#include "Character.hpp"', '#include "Character.hpp"', "local include"),
+        (823, 927, "void my_command(){", "}", "keyboard (kbhit/getch) and command_list()"),
+        (939, 963, "void get_my_action(){", "}", "my_command(), render_it(), printer"),
+        (1014, 1057, "void command_list(bool b = false){", "}", "printer"),
+        (1102, 1229, "bool check_end(){", "}", "printer, render_it(), getch around the end conditions"),
+        (1420, 1426, "void render_it(){", "}", "starts print_game on a thread"),
+        (1428, 1505, "void play(){", "}", "printer.start/stop, get_my_action, check_end, render_it; its call ORDER is restated in ref_tick_main.cpp"),
+        (1507, 1678, "void open(){", "}", "menus: head(), usleep, play()"),
+        (1944, 2067, "void gameplay::print_game() const{", "}", "printer.render, head(), usleep"),
+    ],
+    "bots/bot-0.5/Custom.hpp": [(25, 25, '#include "../../gameplay.hpp"', '#include "../../gameplay.hpp"', "local include")],
+}
+# lines that must be where the recipe thinks they are (the constructs the pins rest on)
+CONTEXT = [
+    ("gameplay.hpp", 37, "int constexpr F = 3, N = 30, M = 100, H = 9000, Z = 9000, B = 9000, C = 9000, lim_portal = 1000, lim_block = 1100;"),
+    ("gameplay.hpp", 437, "struct gameplay{"),
+    ("gameplay.hpp", 654, "void zombie_action(){"),
+    ("gameplay.hpp", 695, "void obey(const char c, Environment::Character::Human &player){"),
+    ("gameplay.hpp", 965, "void human_action(){"),
+    ("gameplay.hpp", 1059, "void update_bull(){"),
+    ("gameplay.hpp", 1231, "void setup(){"),
+    ("gameplay.hpp", 1739, "} g;"),
+    ("gameplay.hpp", 1741, "void gameplay::load_data(){"),
+    ("gameplay.hpp", 1927, "char gameplay::human_rnpc_bot(Environment::Character::Human& player) const{"),
+    ("Character.hpp", 289, "class Human: public Character{"),
+    ("Character.hpp", 873, "void gen_human(bool rnpc, Human &h, int lvl, std::vector<int> cor_, std::string name = \"\", std::string dir = \"\"){"),
+    ("bots/bot-0.5/Custom.hpp", 29, "std::vector<float> describe(const node &cell, const Environment::Character::Human &player){"),
+    ("bots/bot-0.5/Custom.hpp", 137, "char gameplay::bot(Environment::Character::Human& player) const {"),
+]
+
+
+def copy_name(rel):
+    return "ref_" + rel.replace("/", "_").replace("-", "_").replace(".hpp", ".inc")
+
+
+def manifest():
+    rows = []
+    for rel, om in OMIT.items():
+        for first, last, a0, _a1, why in om:
+            rows.append("%-24s %4d-%-4d %-60s %s" % (rel, first, last, a0[:60], why))
+    return "\n".join(rows)
+
+
+def build(ref="/root/reference", quiet=False, flavour=""):
+    base = os.path.join(ref, CLIENT)
+    if not os.path.isfile(os.path.join(base, "gameplay.hpp")):
+        if not quiet:
+            print("no reference checkout at %s: oracle/_ref/sf_ref_tick left as is" % ref)
+        return None
+    main = os.path.join(HERE, "ref_tick_main.cpp")
+    srcs = [os.path.join(base, rel) for rel in OMIT] + [main, os.path.abspath(__file__)]
+    if os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(p) for p in srcs):
+        return OUT
+    tmp = tempfile.mkdtemp(prefix="sf_reftick_")
+    try:
+        kept_total = omitted_total = 0
+        for rel, om in OMIT.items():
+            with open(os.path.join(base, rel), encoding="utf-8", errors="replace", newline="") as f:
+                lines = f.read().replace("\r\n", "\n").split("\n")
+
+            def check(no, text):
+                got = lines[no - 1].strip()
+                if got != text:
+                    raise SystemExit("ref_tick: %s:%d is %r, expected %r — the reference's lines have moved" % (rel, no, got, text))
+
+            for r2, no, text in CONTEXT:
+                if r2 == rel:
+                    check(no, text)
+            for first, last, a0, a1, _why in om:
+                check(first, a0)
+                check(last, a1)
+                for i in range(first - 1, last):
+                    lines[i] = ""
+                omitted_total += last - first + 1
+            kept_total += len(lines)
+            # CRLF -> LF is the only byte-level change (a backslash-CR at a line end would otherwise not continue a line)
+            with open(os.path.join(tmp, copy_name(rel)), "w", encoding="utf-8", newline="") as f:
+                f.write("\n".join(lines) + "\n")
+        # basic.hpp:43 `#include "macros.hpp"` resolves beside the copy
+        shutil.copy(os.path.join(tmp, copy_name("macros.hpp")), os.path.join(tmp, "macros.hpp"))
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        cmd = ["g++", "-std=c++17", "-O2", "-w", "-pthread", "-I", tmp, main, "-o", OUT]
+        subprocess.check_call(cmd)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if not quiet:
+        print("built oracle/_ref/sf_ref_tick from %s (%d lines of 7 client files, %d of them blanked: SFML / keyboard / menus)"
+              % (ref, kept_total, omitted_total))
+    return OUT
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default=os.environ.get("REF", "/root/reference"))
+    ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--manifest", action="store_true", help="print the omitted ranges and why")
+    a = ap.parse_args()
+    if a.manifest:
+        print(manifest())
+    else:
+        build(a.ref, a.quiet)
+    sys.exit(0)

@@ -1,0 +1,260 @@
+// ref_tick_main.cpp — TEST INFRASTRUCTURE (ours): a head-less driver around the reference's own tick path.
+//
+// The ref_*.inc files are the reference's basic.hpp, random.hpp, Item.hpp, Character.hpp, gameplay.hpp and
+// bots/bot-0.5/Custom.hpp with the ranges listed in oracle/ref_tick.py blanked (SFML, keyboard, menus) and every other
+// line unedited.  Nothing in this file restates game logic.  What it does restate, and only this:
+//   * the ORDER of calls in gameplay::play()           gameplay.hpp:1441-1471   (play() itself drives the screen)
+//   * get_my_action's fetch of the player's command     gameplay.hpp:955-958
+//   * main()'s two start-up calls                       main.cpp:29-30
+// `class Agent` is the class the reference leaves to the user (random.hpp:25 -> selected_agent.hpp:25; minimal form
+// bots/bot-0/Agent.hpp:27-37; predict/update signatures bots/bot-0.5/Agent.hpp:178,217): here it plays back scripted
+// actions and records what it was called with.
+//
+// Protocol: one command per line on stdin, one answer block per command on stdout, each block ended by a line "end".
+//   init <profile file> <Solo|Timer|Squad> <level> <agents 0|1>
+//   reset <tb> <serial>             setup(); _srand(tb, serial); ++frame; loop-top spawns
+//   step <chars>                    one iteration of play()'s loop + the next loop top; chars[0] = the player's command,
+//                                   chars[k] = the scripted action of agent k (agents mode)
+//   dump <H> <Z> <B> <P>            state of the first H/Z/B/P slots and of every cell, in sf_*_rec word order
+//   calls                           predict/update calls since the last `calls`
+//   obs <agent id>                  the observation that agent's last predict() received (30752 hex words)
+//   observe <slot>                  Custom.hpp's window encoding for hum[slot] now (through a probe agent)
+//   quit
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+class Agent {
+public:
+    int id;
+    Agent();
+    ~Agent();
+    int predict(const std::vector<float> &obs);
+    void update(int action, bool imitate);
+    bool in_training() { return false; }
+    bool is_manual() { return false; }
+};
+
+#include "ref_basic.inc"
+#include "ref_random.inc"
+#include "ref_Item.inc"
+#include "ref_Character.inc"
+#include "ref_gameplay.inc"
+#include "ref_bots_bot_0.5_Custom.inc"
+
+namespace {
+using namespace Environment::Field;
+namespace CH = Environment::Character;
+
+struct Call { int id; char kind; int a, b; long long frame; };
+std::vector<Call> calls;
+std::map<int, std::vector<float>> last_obs;
+std::map<int, char> script;        // agent id -> the command char it will answer with
+int next_id = 0, live_agents = 0;
+bool probing = false;
+std::vector<float> probe_obs;
+long long steps = 0;
+}  // namespace
+
+Agent::Agent() : id(probing ? -1 : next_id++) {
+    if (id >= 0) ++live_agents, calls.push_back({id, 'N', 0, 0, g.frame});
+}
+Agent::~Agent() {
+    if (id >= 0) --live_agents, calls.push_back({id, 'D', 0, 0, g.frame});
+}
+
+int Agent::predict(const std::vector<float> &obs) {
+    if (probing) { probe_obs = obs; return 0; }
+    last_obs[id] = obs;
+    char c = script.count(id) ? script[id] : '+';
+    int act = 0;
+    for (int i = 0; i < (int)g.action.size(); ++i)
+        if (g.action[i] == c) act = i;
+    calls.push_back({id, 'P', act, (int)obs.size(), g.frame});
+    return act;
+}
+
+void Agent::update(int action, bool imitate) { calls.push_back({id, 'U', action, (int)imitate, g.frame}); }
+
+namespace {
+
+void loop_top() {  // gameplay.hpp:1444-1449
+    if (g.frame % g.pc <= 1) g.spawn_chest();
+    if (g.frame % g.pz <= 1) g.spawn_zombie_npc();
+    if (g.frame % g.ph <= 1) g.spawn_human_npc();
+}
+
+void half_tick() {  // gameplay.hpp:1457-1463 == 1465-1471 (view / find_recom / render_it draw; `start` is the frame clock)
+    g.update_tmp();
+    g.hit_human(), g.hit_zombie();
+    ++g.frame;
+    g.updmap();
+    g.update_bull();
+}
+
+void one_step(const std::string &cmds) {
+    for (size_t k = 0; k < cmds.size(); ++k) script[(int)k] = cmds[k];
+    // get_my_action, gameplay.hpp:955-958 (my_command = the keyboard: the scripted char is what was "typed")
+    command[ind] = cmds.empty() ? '+' : cmds[0];
+    if (using_an_agent) {
+        char c = g.bot(hum[ind]);
+        if (!g.manual && command[ind] != '3') command[ind] = c;
+    }
+    g.zombie_action();   // gameplay.hpp:1455
+    g.portal_damage();   // :1456
+    half_tick();         // :1457-1463
+    g.human_action();    // :1464
+    half_tick();         // :1465-1471
+    ++steps;
+    loop_top();          // the next iteration's :1444-1449
+}
+
+// The state in the word order of include/strikeforce.h's dump records (sf_human_rec 28 words with `profile` = -1: the
+// reference has no such field; sf_zombie_rec 7, sf_bullet_rec 11, sf_portal_rec 4; dead zombie / bullet / exit slots as
+// zeros), one line per table, then the cells: flag byte per cell as hex (SF_CELL_* bits), damage and exit number sparse.
+void dump(int H_, int Z_, int B_, int P_) {
+    printf("hdr %lld %lld %lld %lld %lld %lld %lld %d", g.frame, g.kills, g.teams_kills, g.loot, g.chest,
+           Environment::Random::jomle, steps, ind);
+    for (int i = 0; i < 18; ++i) printf(" %lld", Environment::Random::random[i]);
+    printf("\nH");
+    for (int i = 0; i < H_; ++i) {
+        CH::Human &h = hum[i];
+        auto c = h.get_cor();
+        if (c.size() < 3) c = {0, 0, 0};
+        printf(" %d %d %d -1 %d %d %d %d %d %d %d %d %d %d %d %d %d", (int)mh[i], (int)remote[i], (int)h.is_rnpc(), c[0],
+               c[1], c[2], h.get_way(), h.get_team(), h.get_Hp(), h.get_stamina(), h.get_mindamage(), h.get_kills(),
+               h.get_damage(), h.get_effect(), h.backpack.vec, h.backpack.ind);
+        for (int k = 0; k < 4; ++k) printf(" %d", h.backpack.list_cons[k].second);
+        for (int k = 0; k < 4; ++k) printf(" %d", h.backpack.list_throw[k].second.second);
+        printf(" %d %d %d", h.backpack.get_blocks(), h.backpack.get_portals(), h.backpack.get_portal_ind());
+    }
+    printf("\nA");  // Human::active_agent per slot (Character.hpp:291)
+    for (int i = 0; i < H_; ++i) printf(" %d", (int)hum[i].get_active_agent());
+    printf("\nZ");
+    for (int i = 0; i < Z_; ++i) {
+        if (!mz[i]) { printf(" 0 0 0 0 0 0 0"); continue; }
+        auto c = zomb[i].get_cor();
+        printf(" 1 %d %d %d %d %d %d", c[0], c[1], c[2], zomb[i].get_Hp(), zomb[i].get_mindamage(), (int)zomb[i].is_super());
+    }
+    printf("\nB");
+    for (int i = 0; i < B_; ++i) {
+        if (!mb[i]) { printf(" 0 0 0 0 0 0 0 0 0 0 0"); continue; }
+        auto c = bull[i].get_cor();
+        auto d = bull[i].get_dcor();
+        int trav = abs(c[0] - d[0]) + abs(c[1] - d[1]) + abs(c[2] - d[2]);
+        uintptr_t o = bull[i].get_owner();
+        int owner = o ? (int)(reinterpret_cast<CH::Human *>(o) - hum) + 1 : 0;
+        const node &n = g.themap[c[0]][c[1]][c[2]];
+        printf(" 1 %d %d %d %d %d %d %d %d %d %d", c[0], c[1], c[2], bull[i].get_way(), trav, bull[i].get_damage(),
+               bull[i].get_effect(), bull[i].get_range(), owner, (int)(n.s[2] && n.bullet == &bull[i]));
+    }
+    printf("\nP");
+    for (int i = 0; i < P_; ++i) {
+        if (!active[i]) { printf(" 0 0 0 0"); continue; }
+        printf(" 1 %d %d %d", portal[i][0], portal[i][1], portal[i][2]);
+    }
+    long long over = 0;  // live entities beyond the dumped slots: the caller's caps are too small for this run
+    for (int i = H_; i < H; ++i) over += mh[i];
+    for (int i = Z_; i < Z; ++i) over += mz[i];
+    for (int i = B_; i < B; ++i) over += mb[i];
+    for (int i = P_; i < B; ++i) over += active[i];
+    printf("\nover %lld\nF ", over);
+    std::string sparse;
+    char buf[64];
+    for (int f = 0; f < F; ++f)
+        for (int r = 0; r < N; ++r)
+            for (int c = 0; c < M; ++c) {
+                const node &n = g.themap[f][r][c];
+                int fl = 0;
+                if (n.s[3]) fl |= 1;    // SF_CELL_WALL
+                if (n.s[10]) fl |= 2;   // SF_CELL_TEMP
+                if (n.s[5]) fl |= 4;    // SF_CELL_PIN_UP
+                if (n.s[6]) fl |= 8;    // SF_CELL_PIN_DN
+                if (n.s[7]) fl |= 16;   // SF_CELL_POUT
+                if (n.s[4]) fl |= 32 | ((int)(n.cons - Environment::Item::cons) << 6);  // SF_CELL_CHEST + type
+                printf("%02x", fl);
+                int ci = (f * N + r) * M + c;
+                if (n.s[10] && n.dmg) snprintf(buf, sizeof buf, " d%d:%d", ci, n.dmg), sparse += buf;
+                if (n.s[5] || n.s[6]) snprintf(buf, sizeof buf, " x%d:%d", ci, n.portal_ind), sparse += buf;
+            }
+    printf("\nS%s\n", sparse.c_str());
+}
+
+void print_obs(const std::vector<float> &o) {
+    printf("obs %zu\n", o.size());
+    for (size_t i = 0; i < o.size(); ++i) {
+        uint32_t u;
+        memcpy(&u, &o[i], 4);
+        if (u) printf("%zx:%x\n", i, u);
+    }
+}
+
+}  // namespace
+
+int main() {
+    Environment::Item::download_items();  // main.cpp:29
+    Environment::Random::make_p();        // main.cpp:30
+    char line[4096];
+    while (fgets(line, sizeof line, stdin)) {
+        std::string s(line);
+        while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back();
+        if (s.rfind("init ", 0) == 0) {
+            char path[2048], mode[64];
+            int level, agents;
+            if (sscanf(s.c_str() + 5, "%2047s %63s %d %d", path, mode, &level, &agents) != 4) { printf("error init\nend\n"); fflush(stdout); continue; }
+            user = "ref_tick";
+            CH::me.build(false, "", path);  // Character.hpp:650 with an explicit file (enter.hpp:43 reads the account's)
+            g.mode = mode, g.level = level, g.manual = !agents;
+            printf("ok dims %d %d %d\n", F, N, M);
+        } else if (s.rfind("reset ", 0) == 0) {
+            long long tb, serial;
+            sscanf(s.c_str() + 6, "%lld %lld", &tb, &serial);
+            bool agents = !g.manual || using_an_agent;
+            g.manual = !agents;
+            g.chest = 0;  // gameplay.hpp:1234 does not reset it: every reset here is a first game
+            g.setup();    // gameplay.hpp:1231-1277 -> load_data() :1741-1925
+            g.manual = !agents;  // load_data leaves `manual = true` for the keyboard toggle ('3'); agents mode = automate
+            Environment::Random::_srand(tb, serial);  // the explicit seed replaces time()/libc rand, gameplay.hpp:1233,1745-1747
+            steps = 0;
+            ++g.frame;   // gameplay.hpp:1441
+            loop_top();
+            printf("ok\n");
+        } else if (s.rfind("step", 0) == 0) {
+            one_step(s.size() > 5 ? s.substr(5) : std::string());
+            printf("ok\n");
+        } else if (s.rfind("dump ", 0) == 0) {
+            int a, b, c, d;
+            sscanf(s.c_str() + 5, "%d %d %d %d", &a, &b, &c, &d);
+            dump(a, b, c, d);
+        } else if (s == "calls") {
+            for (auto &c : calls) printf("call %d %c %d %d %lld\n", c.id, c.kind, c.a, c.b, c.frame);
+            calls.clear();
+        } else if (s.rfind("obs ", 0) == 0) {
+            print_obs(last_obs[atoi(s.c_str() + 4)]);
+        } else if (s.rfind("observe ", 0) == 0) {
+            // gameplay::bot (Custom.hpp:137-159) on hum[slot], whoever it is: a probe agent receives the vector
+            int slot = atoi(s.c_str() + 8);
+            CH::Human &h = hum[slot];
+            bool had = h.get_active_agent();
+            Agent *old = h.agent;
+            probing = true;
+            Agent probe;
+            h.agent = &probe;
+            h.set_agent_active();
+            g.bot(h);
+            h.agent = old;
+            if (!had) h.reset_agent_active();
+            probing = false;
+            print_obs(probe_obs);
+        } else if (s == "quit") {
+            break;
+        } else {
+            printf("error unknown command\n");
+        }
+        printf("end\n");
+        fflush(stdout);
+    }
+    return 0;
+}
