@@ -25,6 +25,13 @@ Pins (tests/test_ref_tick.py): rows a4-a18 and a20 — Backpack/Human, gen_human
 three spawns, zombie_action, portal_damage, update_tmp, hit_human/hit_zombie, update_bull, human_action / get_command /
 human_rnpc_bot, obey, teleport, claim_chest, setup/load_data (Solo, Timer, Squad), describe + gameplay::bot — on the
 reference's native world (gameplay.hpp:37: 3 floors x 30 x 100, its caps of 9000 never reached).
+
+Patched dimensions (second flavour, `build(dims=(F, N, M, H, Z, B, C))` -> oracle/_ref/sf_ref_tick_<dims>): the
+reference's world size and slot-pool caps are compile-time constants on ONE line, gameplay.hpp:37.  For BASELINE.json's
+configurations (32x32 ... 128x128, caps of 1-64) that line — and only that line — is blanked as well and
+ref_tick_main.cpp declares the same nine constants with the requested values (`lim_portal` / `lim_block` keep the
+reference's 1000 / 1100): the procedure SURVEY §8c prescribes ("G:37 is the only line to change").  With the caps equal
+to the configuration's, the slot allocators running dry is pinned too.  The native build stays the primary pin.
 """
 import argparse
 import os
@@ -100,16 +107,29 @@ def manifest():
     return "\n".join(rows)
 
 
-def build(ref="/root/reference", quiet=False, flavour=""):
+DIMS_LINE = ("gameplay.hpp", 37)
+
+
+def binary_for(dims=None):
+    if dims is None or tuple(dims) == (3, 30, 100, 9000, 9000, 9000, 9000):
+        return OUT
+    return OUT + "_" + "_".join(str(int(d)) for d in dims)
+
+
+def build(ref="/root/reference", quiet=False, dims=None):
+    """dims None: the reference as it stands.  dims (F, N, M, H, Z, B, C): gameplay.hpp:37 blanked too, its constants
+    declared with these values by ref_tick_main.cpp (-DSF_REF_DIMS)."""
     base = os.path.join(ref, CLIENT)
+    out = binary_for(dims)
+    patched = out != OUT
     if not os.path.isfile(os.path.join(base, "gameplay.hpp")):
         if not quiet:
-            print("no reference checkout at %s: oracle/_ref/sf_ref_tick left as is" % ref)
+            print("no reference checkout at %s: %s left as is" % (ref, os.path.relpath(out, os.path.dirname(HERE))))
         return None
     main = os.path.join(HERE, "ref_tick_main.cpp")
     srcs = [os.path.join(base, rel) for rel in OMIT] + [main, os.path.abspath(__file__)]
-    if os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(p) for p in srcs):
-        return OUT
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(p) for p in srcs):
+        return out
     tmp = tempfile.mkdtemp(prefix="sf_reftick_")
     try:
         kept_total = omitted_total = 0
@@ -125,6 +145,10 @@ def build(ref="/root/reference", quiet=False, flavour=""):
             for r2, no, text in CONTEXT:
                 if r2 == rel:
                     check(no, text)
+            om = list(om)
+            if patched and rel == DIMS_LINE[0]:
+                text = [t for r2, no, t in CONTEXT if r2 == rel and no == DIMS_LINE[1]][0]
+                om.append((DIMS_LINE[1], DIMS_LINE[1], text, text, "patched dimensions"))
             for first, last, a0, a1, _why in om:
                 check(first, a0)
                 check(last, a1)
@@ -137,15 +161,17 @@ def build(ref="/root/reference", quiet=False, flavour=""):
                 f.write("\n".join(lines) + "\n")
         # basic.hpp:43 `#include "macros.hpp"` resolves beside the copy
         shutil.copy(os.path.join(tmp, copy_name("macros.hpp")), os.path.join(tmp, "macros.hpp"))
-        os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        cmd = ["g++", "-std=c++17", "-O2", "-w", "-pthread", "-I", tmp, main, "-o", OUT]
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        cmd = ["g++", "-std=c++17", "-O2", "-w", "-pthread", "-I", tmp, main, "-o", out]
+        if patched:
+            cmd += ["-DSF_REF_DIMS=%s" % ",".join(str(int(d)) for d in dims)]
         subprocess.check_call(cmd)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     if not quiet:
-        print("built oracle/_ref/sf_ref_tick from %s (%d lines of 7 client files, %d of them blanked: SFML / keyboard / menus)"
-              % (ref, kept_total, omitted_total))
-    return OUT
+        print("built oracle/_ref/%s from %s (%d lines of 7 client files, %d of them blanked: SFML / keyboard / menus%s)"
+              % (os.path.basename(out), ref, kept_total, omitted_total, " + gameplay.hpp:37, the dimensions" if patched else ""))
+    return out
 
 
 if __name__ == "__main__":
@@ -153,9 +179,10 @@ if __name__ == "__main__":
     ap.add_argument("--ref", default=os.environ.get("REF", "/root/reference"))
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--manifest", action="store_true", help="print the omitted ranges and why")
+    ap.add_argument("--dims", default="", help="F,N,M,H,Z,B,C: also blank gameplay.hpp:37 and compile for these")
     a = ap.parse_args()
     if a.manifest:
         print(manifest())
     else:
-        build(a.ref, a.quiet)
+        build(a.ref, a.quiet, [int(x) for x in a.dims.split(",")] if a.dims else None)
     sys.exit(0)

@@ -38,6 +38,15 @@ public:
 };
 
 #include "ref_basic.inc"
+#ifdef SF_REF_DIMS
+// Patched-dimensions flavour only (oracle/ref_tick.py): gameplay.hpp:37 is blanked in the copy and its nine constants
+// are declared here with the requested sizes; lim_portal / lim_block keep the reference's values.
+namespace Environment::Field {
+constexpr int sf_ref_dims[7] = {SF_REF_DIMS};
+int constexpr F = sf_ref_dims[0], N = sf_ref_dims[1], M = sf_ref_dims[2], H = sf_ref_dims[3], Z = sf_ref_dims[4],
+              B = sf_ref_dims[5], C = sf_ref_dims[6], lim_portal = 1000, lim_block = 1100;
+}
+#endif
 #include "ref_random.inc"
 #include "ref_Item.inc"
 #include "ref_Character.inc"
@@ -207,7 +216,7 @@ int main() {
             user = "ref_tick";
             CH::me.build(false, "", path);  // Character.hpp:650 with an explicit file (enter.hpp:43 reads the account's)
             g.mode = mode, g.level = level, g.manual = !agents;
-            printf("ok dims %d %d %d\n", F, N, M);
+            printf("ok dims %d %d %d %d %d %d %d\n", F, N, M, H, Z, B, C);
         } else if (s.rfind("reset ", 0) == 0) {
             long long tb, serial;
             sscanf(s.c_str() + 6, "%lld %lld", &tb, &serial);

@@ -17,18 +17,42 @@ REF_CLIENT = "/root/reference/StrikeForce-client"
 MODES = {abi.MODE_SOLO: "Solo", abi.MODE_TIMER: "Timer", abi.MODE_SQUAD: "Squad"}
 
 
+NATIVE = (3, 30, 100, 9000, 9000, 9000, 9000)  # gameplay.hpp:37
+
+
 def available():
     return os.path.exists(BIN) and os.path.isdir(os.path.join(REF_CLIENT, "Items"))
 
 
+def binary(dims):
+    """The build for these dimensions: the native one as __graft_entry__.build() left it; a patched-dimensions one
+    (gameplay.hpp:37 replaced, oracle/ref_tick.py) is compiled on first use where the checkout exists."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_tick
+    path = ref_tick.binary_for(dims)
+    if path != BIN and os.path.isdir(REF_CLIENT):
+        ref_tick.build(quiet=True, dims=dims)
+    return path if os.path.exists(path) else None
+
+
 class RefTick:
     """One reference game in a child process.  `workload`: a config.Workload with the reference's native dimensions
-    (3 x 30 x 100, gameplay.hpp:37), mode Solo / Timer / Squad; its map is written out as map/floor1-3.txt in the
+    (3 x 30 x 100, gameplay.hpp:37) or any other (a patched-dimensions build), mode Solo / Timer / Squad; its map is written out as map/floor1-3.txt in the
     reference's own text format and read back by gameplay::setup()."""
 
-    def __init__(self, workload, player_tokens, agents=False):
+    def __init__(self, workload, player_tokens, agents=False, native_caps=True):
+        """native_caps: the reference's own slot pools of 9000 (the run must stay within the configuration's caps:
+        `over`); False: a build whose pools are the configuration's, so that they run dry at the same moment."""
         cfg = workload.cfg
-        assert (cfg.floors, cfg.rows, cfg.cols) == (3, 30, 100), "the reference is compiled for 3 x 30 x 100"
+        dims = (cfg.floors, cfg.rows, cfg.cols)
+        if native_caps:
+            dims += (9000, 9000, 9000, 9000)
+        else:  # (the reference pools exits by B as well, `portal[B]` gameplay.hpp:51-53: `over` counts exits beyond cap_portals)
+            dims += (cfg.cap_humans, cfg.cap_zombies, cfg.cap_bullets, cfg.cap_chests)
+        self.p = None
+        exe = binary(dims)
+        assert exe, "no sf_ref_tick build for %s" % (dims,)
         self.cfg = cfg
         self.dir = tempfile.mkdtemp(prefix="sf_reftick_run_")
         os.makedirs(os.path.join(self.dir, "map"))
@@ -37,15 +61,15 @@ class RefTick:
         cells = cfg.rows * cfg.cols
         chars = bytes(workload._map.raw).decode("ascii")
         portal = list(workload._portal)
-        for f in range(3):
+        for f in range(cfg.floors):
             with open(os.path.join(self.dir, "map", "floor%d.txt" % (f + 1)), "w") as fh:
                 fh.write(config.format_floor_text(chars[f * cells:(f + 1) * cells], portal[f * cells:(f + 1) * cells],
                                                   cfg.rows, cfg.cols))
         with open(os.path.join(self.dir, "profile.txt"), "w") as fh:
             fh.write("player\n" + "\n".join(str(int(t)) for t in player_tokens) + "\n")
-        self.p = subprocess.Popen([BIN], cwd=self.dir, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+        self.p = subprocess.Popen([exe], cwd=self.dir, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
         r = self._cmd("init profile.txt %s %d %d" % (MODES[cfg.mode], cfg.level, int(agents)))
-        assert r and r[0] == "ok dims 3 30 100", r
+        assert r and r[0] == "ok dims " + " ".join(str(d) for d in dims), r
 
     def _cmd(self, line):
         self.p.stdin.write(line + "\n")
