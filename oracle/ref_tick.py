@@ -110,18 +110,23 @@ def manifest():
 DIMS_LINE = ("gameplay.hpp", 37)
 
 
-def binary_for(dims=None):
-    if dims is None or tuple(dims) == (3, 30, 100, 9000, 9000, 9000, 9000):
-        return OUT
-    return OUT + "_" + "_".join(str(int(d)) for d in dims)
+NATIVE_DIMS = (3, 30, 100, 9000, 9000, 9000, 9000)
 
 
-def build(ref="/root/reference", quiet=False, dims=None):
+def binary_for(dims=None, squad_agents=False):
+    out = OUT + ("_squadagents" if squad_agents else "")
+    if dims is None or tuple(dims) == NATIVE_DIMS:
+        return out
+    return out + "_" + "_".join(str(int(d)) for d in dims)
+
+
+def build(ref="/root/reference", quiet=False, dims=None, squad_agents=False):
     """dims None: the reference as it stands.  dims (F, N, M, H, Z, B, C): gameplay.hpp:37 blanked too, its constants
-    declared with these values by ref_tick_main.cpp (-DSF_REF_DIMS)."""
+    declared with these values by ref_tick_main.cpp (-DSF_REF_DIMS).  squad_agents: compiled with the reference's own
+    switch USE_AGENT_IN_SQUAD_NPCS (gameplay.hpp:1883,1896: every Squad human gets an Agent)."""
     base = os.path.join(ref, CLIENT)
-    out = binary_for(dims)
-    patched = out != OUT
+    out = binary_for(dims, squad_agents)
+    patched = not (dims is None or tuple(dims) == NATIVE_DIMS)
     if not os.path.isfile(os.path.join(base, "gameplay.hpp")):
         if not quiet:
             print("no reference checkout at %s: %s left as is" % (ref, os.path.relpath(out, os.path.dirname(HERE))))
@@ -165,6 +170,8 @@ def build(ref="/root/reference", quiet=False, dims=None):
         cmd = ["g++", "-std=c++17", "-O2", "-w", "-pthread", "-I", tmp, main, "-o", out]
         if patched:
             cmd += ["-DSF_REF_DIMS=%s" % ",".join(str(int(d)) for d in dims)]
+        if squad_agents:
+            cmd += ["-DUSE_AGENT_IN_SQUAD_NPCS"]
         subprocess.check_call(cmd)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -180,9 +187,12 @@ if __name__ == "__main__":
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--manifest", action="store_true", help="print the omitted ranges and why")
     ap.add_argument("--dims", default="", help="F,N,M,H,Z,B,C: also blank gameplay.hpp:37 and compile for these")
+    ap.add_argument("--squad-agents", action="store_true", help="compile with -DUSE_AGENT_IN_SQUAD_NPCS")
     a = ap.parse_args()
     if a.manifest:
         print(manifest())
     else:
-        build(a.ref, a.quiet, [int(x) for x in a.dims.split(",")] if a.dims else None)
+        build(a.ref, a.quiet, [int(x) for x in a.dims.split(",")] if a.dims else None, a.squad_agents)
+        if not a.dims and not a.squad_agents:  # the default call (oracle/Makefile `ref`) also makes the Squad-agents flavour
+            build(a.ref, a.quiet, None, True)
     sys.exit(0)

@@ -95,12 +95,17 @@ void loop_top() {  // gameplay.hpp:1444-1449
     if (g.frame % g.ph <= 1) g.spawn_human_npc();
 }
 
-void half_tick() {  // gameplay.hpp:1457-1463 == 1465-1471 (view / find_recom / render_it draw; `start` is the frame clock)
+long long phase_draws[6];
+
+void half_tick(int k) {  // gameplay.hpp:1457-1463 == 1465-1471 (view / find_recom / render_it draw; `start` is the frame clock)
+    long long &j = Environment::Random::jomle, j0 = j;
     g.update_tmp();
     g.hit_human(), g.hit_zombie();
+    phase_draws[5] += j - j0, j0 = j;
     ++g.frame;
     g.updmap();
     g.update_bull();
+    phase_draws[k] = j - j0;
 }
 
 void one_step(const std::string &cmds) {
@@ -111,13 +116,22 @@ void one_step(const std::string &cmds) {
         char c = g.bot(hum[ind]);
         if (!g.manual && command[ind] != '3') command[ind] = c;
     }
+    // draws per phase (the generator's own counter, random.hpp:29): zombie_action, update_bull (1st), human_action,
+    // update_bull (2nd), the next loop top, everything else
+    long long &j = Environment::Random::jomle, j0 = j;
+    for (auto &x : phase_draws) x = 0;
     g.zombie_action();   // gameplay.hpp:1455
+    phase_draws[0] = j - j0, j0 = j;
     g.portal_damage();   // :1456
-    half_tick();         // :1457-1463
+    half_tick(1);        // :1457-1463
+    j0 = j;
     g.human_action();    // :1464
-    half_tick();         // :1465-1471
+    phase_draws[2] = j - j0, j0 = j;
+    half_tick(3);        // :1465-1471
+    j0 = j;
     ++steps;
     loop_top();          // the next iteration's :1444-1449
+    phase_draws[4] = j - j0;
 }
 
 // The state in the word order of include/strikeforce.h's dump records (sf_human_rec 28 words with `profile` = -1: the
@@ -232,7 +246,8 @@ int main() {
             printf("ok\n");
         } else if (s.rfind("step", 0) == 0) {
             one_step(s.size() > 5 ? s.substr(5) : std::string());
-            printf("ok\n");
+            printf("ok %lld %lld %lld %lld %lld %lld\n", phase_draws[0], phase_draws[1], phase_draws[2], phase_draws[3],
+                   phase_draws[4], phase_draws[5]);
         } else if (s.rfind("dump ", 0) == 0) {
             int a, b, c, d;
             sscanf(s.c_str() + 5, "%d %d %d %d", &a, &b, &c, &d);

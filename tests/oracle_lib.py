@@ -39,6 +39,8 @@ def lib():
         L.sfo_kat_zombie.restype = None
         L.sfo_draws.argtypes = [C.c_void_p, C.c_int32]
         L.sfo_draws.restype = C.c_int64
+        L.sfo_phase_draws.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+        L.sfo_phase_draws.restype = None
         L.sfo_bench_run.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]
         L.sfo_bench_run.restype = C.c_int64
         L.sfo_event_count.restype = C.c_int32
@@ -159,6 +161,13 @@ class Oracle:
 
     def draws(self, arena):
         return self.L.sfo_draws(self.h, arena)
+
+    def phase_draws(self, arena):
+        """Generator draws of the arena's last step: [zombie_action, update_bull (1st), human_action, update_bull (2nd),
+        the next loop top's spawns, everything else (0)]."""
+        out = (C.c_int64 * 6)()
+        self.L.sfo_phase_draws(self.h, arena, out)
+        return list(out)
 
     def events(self):
         """Branch-coverage counters summed over all arenas: {name: count}."""

@@ -24,15 +24,15 @@ def available():
     return os.path.exists(BIN) and os.path.isdir(os.path.join(REF_CLIENT, "Items"))
 
 
-def binary(dims):
+def binary(dims, squad_agents=False):
     """The build for these dimensions: the native one as __graft_entry__.build() left it; a patched-dimensions one
     (gameplay.hpp:37 replaced, oracle/ref_tick.py) is compiled on first use where the checkout exists."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref_tick
-    path = ref_tick.binary_for(dims)
+    path = ref_tick.binary_for(dims, squad_agents)
     if path != BIN and os.path.isdir(REF_CLIENT):
-        ref_tick.build(quiet=True, dims=dims)
+        ref_tick.build(quiet=True, dims=dims, squad_agents=squad_agents)
     return path if os.path.exists(path) else None
 
 
@@ -41,7 +41,7 @@ class RefTick:
     (3 x 30 x 100, gameplay.hpp:37) or any other (a patched-dimensions build), mode Solo / Timer / Squad; its map is written out as map/floor1-3.txt in the
     reference's own text format and read back by gameplay::setup()."""
 
-    def __init__(self, workload, player_tokens, agents=False, native_caps=True):
+    def __init__(self, workload, player_tokens, agents=False, native_caps=True, squad_agents=False):
         """native_caps: the reference's own slot pools of 9000 (the run must stay within the configuration's caps:
         `over`); False: a build whose pools are the configuration's, so that they run dry at the same moment."""
         cfg = workload.cfg
@@ -51,7 +51,7 @@ class RefTick:
         else:  # (the reference pools exits by B as well, `portal[B]` gameplay.hpp:51-53: `over` counts exits beyond cap_portals)
             dims += (cfg.cap_humans, cfg.cap_zombies, cfg.cap_bullets, cfg.cap_chests)
         self.p = None
-        exe = binary(dims)
+        exe = binary(dims, squad_agents)
         assert exe, "no sf_ref_tick build for %s" % (dims,)
         self.cfg = cfg
         self.dir = tempfile.mkdtemp(prefix="sf_reftick_run_")
@@ -105,7 +105,11 @@ class RefTick:
         """chars: bytes/str, chars[0] the player's command, chars[k] agent k's scripted action."""
         if isinstance(chars, (bytes, bytearray, np.ndarray)):
             chars = bytes(chars).decode("ascii")
-        assert self._cmd("step " + chars) == ["ok"]
+        r = self._cmd("step " + chars)
+        assert len(r) == 1 and r[0].startswith("ok "), r
+        # generator draws of this step by phase: zombie_action, update_bull (1st), human_action, update_bull (2nd),
+        # the next loop top's spawns, everything else
+        self.phase_draws = [int(x) for x in r[0].split()[1:]]
 
     def calls(self):
         """[(agent id, 'N'ew|'D'eleted|'P'redict|'U'pdate, a, b, frame)] since the last call."""

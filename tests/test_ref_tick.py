@@ -4,7 +4,8 @@ member functions blanked and every other line unedited (oracle/ref_tick.py lists
 head-less in play()'s order (oracle/ref_tick_main.cpp).  The reference is compiled for its native world (gameplay.hpp:37:
 3 floors x 30 x 100), so these runs use that shape: the shipped maps and synthetic ones, Solo / Timer / Squad, three
 character records, levels 1-4.  After EVERY step the whole state is compared: every field of every human, zombie, bullet
-and exit slot, every cell's bits, damage and exit number, the counters, the generator's 18 registers and its draw count.
+and exit slot, every cell's bits, damage and exit number, the counters, the generator's 18 registers and its draw count
+— and the number of draws each phase of the step made (zombie_action, the two update_bull, human_action, the spawns).
 
 This pins SURVEY §8 rows a4-a18 and a20 on the reference itself (a1-a3: tests/test_ref_slices.py).  Not in the build,
 hence not pinned here: check_end (a19; it is screens and key waits around its comparisons) and the online branch of
@@ -50,6 +51,9 @@ def lockstep(w, player, tb, serial, steps, cmd_seed, observe_every=0, min_steps=
             rd = r.dump()
             if r.over:  # more live entities than the configuration's caps hold (the reference's own are 9000): stop here
                 break
+            # SURVEY §8c golden item 5: the draws of every phase of every step (pins the ORDER in which phases draw)
+            assert o.phase_draws(0) == r.phase_draws, "step %d: draws per phase %s, the reference's %s" % (s, o.phase_draws(0), r.phase_draws)
+            assert r.phase_draws[5] == 0 and r.phase_draws[1] == 1 and r.phase_draws[3] == 1
             d = reftick.first_difference(rd, reftick.arrays_of(od))
             assert d is None, "step %d (command %r): %s" % (s, chr(cmds[s, 0, 0]), d)
             done = s + 1
