@@ -7,7 +7,14 @@
  *   gameplay::prepare(Human&)   bots/bot-0.5/Custom.hpp:161-165  -> set `action`, `new Agent()`
  *   gameplay::bot(Human&)       bots/bot-0.5/Custom.hpp:137-159  -> obs (32x31x31 floats) -> predict() -> action[idx]
  *   human_action()              gameplay.hpp:970-976,991-997     -> agent->update(act, manual)
- *   deleteAgent()               Character.hpp:333-338, gameplay.hpp:648-649,1477
+ *   deleteAgent()               Character.hpp:333-338, gameplay.hpp:648-649,1477 -> a human that dies loses its Agent
+ *                               (sf_agent_alive) and is never asked again (gameplay.hpp:985,991)
+ * Call order of one iteration, as in the reference (gameplay.hpp:955-958,970-999):
+ *   predict(ind) on the loop-top state; zombie_action ... first update_bull; update(ind); then for every other living
+ *   agent in slot order predict(i) on THAT state, update(i); then the humans' sweep.
+ * Agents other than `ind` in one process exist only in Squad mode built with USE_AGENT_IN_SQUAD_NPCS
+ * (gameplay.hpp:1883-1885,1896-1898); there the adapter uses sf_step_begin / sf_step_end.  In Battle mode every agent
+ * is the `ind` of its own client process and observes at its own loop top: one sf_observe, one sf_step.
  * The Agent type is the reference's own (e.g. bots/bot-0.5/Agent.hpp): `int predict(const std::vector<float>&)`,
  * `void update(int, bool)`, optional `bool in_training()`, `bool is_manual()`.  bot-0's Agent has no predict();
  * its Custom.hpp returns '+' (bots/bot-0/Custom.hpp:39-41) and so does this adapter.
@@ -54,6 +61,7 @@ class AgentRunner {
     act_.assign(n, 0);
     cmd_.assign(n, (uint8_t)'+');
     done_.assign((size_t)cfg_.arenas, 0);
+    alive_.assign(n, 1);
     obs_.resize(n * SF_OBS_FLOATS);
     one_.resize(SF_OBS_FLOATS);
   }
@@ -71,43 +79,73 @@ class AgentRunner {
 
   /* One iteration of play()'s loop for all arenas.  Returns the number of arenas whose episode ended. */
   int step(bool manual = false) {
+    const size_t na = (size_t)cfg_.n_agents;
+    const bool mid = cfg_.mode == SF_MODE_SQUAD && cfg_.n_agents > 1;  // agents other than `ind` are asked inside human_action
     check(sf_observe(env_, obs_.data()), "sf_observe");
     for (size_t i = 0; i < agents_.size(); ++i) {
       act_[i] = 0;
       cmd_[i] = (uint8_t)'+';
-      if (!agents_[i]) continue;
-      if constexpr (detail::has_predict<AgentT>::value) {
-        /* `obs` is owned by the caller and valid only during predict(), as in Custom.hpp:141-158 */
-        one_.assign(obs_.begin() + (ptrdiff_t)(i * SF_OBS_FLOATS), obs_.begin() + (ptrdiff_t)((i + 1) * SF_OBS_FLOATS));
-        int idx = agents_[i]->predict(one_);
-        if (idx < 0 || idx >= (int)action_.size()) idx = 0;
-        act_[i] = idx;
-        cmd_[i] = (uint8_t)action_[(size_t)idx];
-      }
+      if (!mid || i % na == (size_t)cfg_.ind) ask(i);  // bot(hum[ind]) at the loop top, gameplay.hpp:955-958
     }
-    check(sf_step(env_, cmd_.data()), "sf_step");
-    /* human_action(): `act` = position of the command in `action`, 0 if absent (gameplay.hpp:971-975) */
-    for (size_t i = 0; i < agents_.size(); ++i)
-      if (agents_[i]) agents_[i]->update(act_[i], manual);
+    if (!mid) {
+      check(sf_step(env_, cmd_.data()), "sf_step");
+      /* human_action(): `act` = position of the command in `action`, 0 if absent (gameplay.hpp:971-975) */
+      for (size_t i = 0; i < agents_.size(); ++i)
+        if (agents_[i]) agents_[i]->update(act_[i], manual);
+    } else {
+      check(sf_step_begin(env_), "sf_step_begin");  // zombie_action ... the first update_bull
+      check(sf_agent_alive(env_, alive_.data()), "sf_agent_alive");
+      check(sf_observe(env_, obs_.data()), "sf_observe");
+      for (int a = 0; a < cfg_.arenas; ++a) {
+        const size_t base = (size_t)a * na, me = base + (size_t)cfg_.ind;
+        if (agents_[me]) agents_[me]->update(act_[me], manual);  // gameplay.hpp:970-976
+        for (size_t g = 0; g < na; ++g) {                         // gameplay.hpp:985-999, slot order
+          const size_t i = base + g;
+          if (i == me) continue;
+          if (!alive_[i]) agents_[i].reset();  // shot dead in the first half-tick: deleteAgent, gameplay.hpp:648-649
+          if (!agents_[i]) continue;
+          ask(i);
+          agents_[i]->update(act_[i], false);
+        }
+      }
+      check(sf_step_end(env_, cmd_.data()), "sf_step_end");
+    }
     check(sf_done(env_, done_.data()), "sf_done");
+    check(sf_agent_alive(env_, alive_.data()), "sf_agent_alive");
     int ended = 0;
-    for (int a = 0; a < cfg_.arenas; ++a)
+    for (int a = 0; a < cfg_.arenas; ++a) {
       if (done_[(size_t)a]) {
         ++ended;
         /* end of play(): deleteAgent(); with auto_reset the next episode starts with prepare() again */
-        for (int g = 0; g < cfg_.n_agents; ++g) {
-          auto &slot = agents_[(size_t)a * (size_t)cfg_.n_agents + (size_t)g];
-          slot.reset(cfg_.auto_reset ? new AgentT() : nullptr);
-        }
+        for (size_t g = 0; g < na; ++g) agents_[(size_t)a * na + g].reset(cfg_.auto_reset ? new AgentT() : nullptr);
+      } else {
+        /* hit_human(): a human other than `ind` that died has lost its Agent for good (gameplay.hpp:648-649) */
+        for (size_t g = 0; g < na; ++g)
+          if (!alive_[(size_t)a * na + g] && g != (size_t)cfg_.ind) agents_[(size_t)a * na + g].reset();
       }
+    }
     return ended;
   }
 
   sf_env *env() const { return env_; }
   const std::vector<uint8_t> &last_commands() const { return cmd_; }
   const std::vector<uint8_t> &done() const { return done_; }
+  const std::vector<uint8_t> &alive() const { return alive_; }
+  bool has_agent(int arena, int agent) const { return (bool)agents_[(size_t)arena * (size_t)cfg_.n_agents + (size_t)agent]; }
 
  private:
+  /* gameplay::bot(): obs -> predict() -> action[idx]   bots/bot-0.5/Custom.hpp:137-159 */
+  void ask(size_t i) {
+    if (!agents_[i]) return;
+    if constexpr (detail::has_predict<AgentT>::value) {
+      /* `obs` is owned by the caller and valid only during predict(), as in Custom.hpp:141-158 */
+      one_.assign(obs_.begin() + (ptrdiff_t)(i * SF_OBS_FLOATS), obs_.begin() + (ptrdiff_t)((i + 1) * SF_OBS_FLOATS));
+      int idx = agents_[i]->predict(one_);
+      if (idx < 0 || idx >= (int)action_.size()) idx = 0;
+      act_[i] = idx;
+      cmd_[i] = (uint8_t)action_[(size_t)idx];
+    }
+  }
   static void check(int rc, const char *what) {
     if (rc != SF_OK) throw std::runtime_error(std::string(what) + ": " + sf_last_error());
   }
@@ -116,7 +154,7 @@ class AgentRunner {
   sf_env *env_ = nullptr;
   std::vector<std::unique_ptr<AgentT>> agents_;
   std::vector<int> act_;
-  std::vector<uint8_t> cmd_, done_;
+  std::vector<uint8_t> cmd_, done_, alive_;
   std::vector<float> obs_, one_;
 };
 

@@ -181,6 +181,28 @@ int sf_step(sf_env *env, const uint8_t *cmd);
  * ([k][arenas][n_agents]).  This is the throughput path. */
 int sf_step_device(sf_env *env, const uint8_t *d_cmd, int32_t k);
 
+/* The same iteration in two calls, cut where the reference asks the agents of humans OTHER than `ind` for their command:
+ * get_command(i) -> bot(hum[i]) runs inside human_action (gameplay.hpp:988-999), i.e. after zombie_action ... the first
+ * update_bull (gameplay.hpp:1455-1463), whereas the player `ind` was asked at the loop top (gameplay.hpp:955-958).
+ *   sf_step_begin          gameplay.hpp:1455-1463
+ *   sf_observe...          what bot(hum[i]), i != ind, encodes (only built with USE_AGENT_IN_SQUAD_NPCS does the
+ *                          reference have such agents: Squad mode, gameplay.hpp:1883-1885,1896-1898)
+ *   sf_step_end(cmd)       gameplay.hpp:1464-1471 + the next loop top; cmd as for sf_step (the entry of `ind` being
+ *                          the command chosen at the loop top)
+ * sf_step == sf_step_begin + sf_step_end on the same commands, bit for bit.  Between the two calls only the observe /
+ * dump / digest / agent_alive entry points may be used (SF_ERR_STATE otherwise). */
+int sf_step_begin(sf_env *env);
+int sf_step_end(sf_env *env, const uint8_t *cmd);
+int sf_step_end_device(sf_env *env, const uint8_t *d_cmd);
+
+/* Replaces Human::active_agent / deleteAgent (Character.hpp:291,333-338): out[arenas][n_agents], 1 while the commanded
+ * human is alive and still driven through sf_step.  The reference deletes a dead human's Agent in hit_human
+ * (gameplay.hpp:648-649) and never queries it again (gameplay.hpp:985,991: `mh[i]`, get_active_agent()); its slot may
+ * be handed to a spawned NPC (h_ind, gameplay.hpp:216-221), which then runs on human_rnpc_bot: commands sent for a
+ * dead agent are ignored and its observation is all zero.  (The player `ind` dying ends the episode: sf_done.) */
+int sf_agent_alive(sf_env *env, uint8_t *out_host);
+int sf_agent_alive_device(sf_env *env, uint8_t *d_out);
+
 /* Replaces gameplay::bot() observation encoding, bots/bot-0.5/Custom.hpp:29-159, for every
  * (arena, agent): out[arenas][n_agents][32][31][31] float32. */
 int sf_observe(sf_env *env, float *out_host);
@@ -217,6 +239,8 @@ int sf_results_device(sf_env *env, int32_t *d_out);
 #define SF_COMM_ID_BYTES 128
 int sf_comm_unique_id(uint8_t *id);
 int sf_comm_init(sf_env *env, const uint8_t *id, int32_t rank, int32_t world);
+/* ncclCommCount of the library's communicator: the number of ranks RCCL itself reports (bench.py prints it) */
+int sf_comm_ranks(sf_env *env, int32_t *ranks);
 /* Snapshot this env's result records on its stream and all-gather the snapshots of all ranks into d_out
  * ([world][arenas][n_agents][8] int32, device memory) on a side stream owned by the library: the call returns at
  * once and the gather runs beside the launches that follow.  d_out is complete after sf_comm_wait. */

@@ -148,7 +148,11 @@ def bind(lib, prefix):
     g("dump_arena").argtypes = [vp, C.c_int32, C.POINTER(ArenaHdr), C.POINTER(HumanRec), C.POINTER(ZombieRec),
                                 C.POINTER(BulletRec), C.POINTER(PortalRec), C.POINTER(C.c_uint8),
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-    for n in ("reset", "step", "observe", "results", "done", "state_digest", "dump_arena"):
+    g("step_begin").argtypes = [vp]
+    g("step_end").argtypes = [vp, C.c_char_p]
+    g("agent_alive").argtypes = [vp, C.POINTER(C.c_uint8)]
+    for n in ("reset", "step", "observe", "results", "done", "state_digest", "dump_arena", "step_begin", "step_end",
+              "agent_alive"):
         g(n).restype = C.c_int
     g("destroy").argtypes = [vp]
     return lib

@@ -44,6 +44,22 @@ __global__ __launch_bounds__(64) void k_step(Params p, const uint8_t *cmds, int 
   Core<WaveGfx950, NB, HP, BM>::step_body(lds, p, (int)blockIdx.x, cmds, k);
 }
 
+// sf_step_begin / sf_step_end: one half of one iteration (sf_core.hpp step<1> / step<2>)
+template <int NB, bool HP, bool BM>
+__global__ __launch_bounds__(64) void k_step_half(Params p, const uint8_t *cmds, int phase) {
+  extern __shared__ __attribute__((aligned(2048))) uint8_t lds[];
+  Core<WaveGfx950, NB, HP, BM>::step_half_body(lds, p, (int)blockIdx.x, cmds, phase);
+}
+
+// Human::active_agent of every commanded human (sf_agent_alive): alive and still driven through sf_step
+__global__ void k_agent_alive(Params p, uint8_t *out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= p.A * p.n_agents) return;
+  const int a = i / p.n_agents, g = i % p.n_agents;
+  const uint32_t fl = gptr(p.hum)[((size_t)HW_FLAGS * (size_t)p.A + (size_t)a) * (size_t)p.H + (size_t)g];
+  gptr(out)[i] = (uint8_t)((fl & (HF_ALIVE | HF_CTRL)) == (HF_ALIVE | HF_CTRL));
+}
+
 // check_end()'s verdict per (arena, agent) on the device (sf_done_device)
 __global__ void k_done(Params p, uint8_t *out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -513,6 +529,38 @@ struct HipRT {
       default: return do_step<4>(p, cmds, k);
     }
   }
+  template <int NB>
+  int do_step_half(const Params &p, const uint8_t *cmds, int phase) {
+    const bool hp = hbm_plane(p.cells_pad), bm = use_bitmaps(p.cells_pad);
+    const size_t lds = lds_bytes_for(p.cells_pad, p.lds_tab);
+    if (!hp) {
+      int rc = lds_attr(k_step_half<NB, false, true>, lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_step_half<NB, false, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, phase);
+    } else if (bm) {
+      hipLaunchKernelGGL((k_step_half<NB, true, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, phase);
+    } else {
+      hipLaunchKernelGGL((k_step_half<NB, true, false>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, phase);
+    }
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+  }
+  int launch_step_half(const Params &p, int NB, const uint8_t *cmds, int phase) {
+    SF_HIP(hipSetDevice(device));
+    switch (NB) {
+      case 1: return do_step_half<1>(p, cmds, phase);
+      case 2: return do_step_half<2>(p, cmds, phase);
+      case 3: return do_step_half<3>(p, cmds, phase);
+      default: return do_step_half<4>(p, cmds, phase);
+    }
+  }
+  int launch_agent_alive(const Params &p, uint8_t *d_out) {
+    SF_HIP(hipSetDevice(device));
+    const int n = p.A * p.n_agents;
+    hipLaunchKernelGGL(k_agent_alive, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, d_out);
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+  }
   int launch_done(const Params &p, uint8_t *d_out) {
     SF_HIP(hipSetDevice(device));
     const int n = p.A * p.n_agents;
@@ -568,6 +616,8 @@ struct Comm {
   typedef int (*all_gather_t)(const void *, void *, size_t, int, void *, hipStream_t);
   typedef int (*destroy_t)(void *);
   typedef const char *(*err_t)(int);
+  typedef int (*count_t)(void *, int *);
+  count_t count_fn = nullptr;
   void *dl = nullptr;
   get_id_t get_id = nullptr;
   init_rank_t init_rank = nullptr;
@@ -593,6 +643,7 @@ struct Comm {
     all_gather = (all_gather_t)dlsym(dl, "ncclAllGather");
     destroy_fn = (destroy_t)dlsym(dl, "ncclCommDestroy");
     err = (err_t)dlsym(dl, "ncclGetErrorString");
+    count_fn = (count_t)dlsym(dl, "ncclCommCount");
     if (!get_id || !init_rank || !all_gather || !destroy_fn || !err) return fail(SF_ERR_DEVICE, "RCCL lacks a symbol");
     return SF_OK;
   }
@@ -693,6 +744,26 @@ int sf_done(sf_env *env, uint8_t *out_host) {
   SF_ENV(env);
   return env->e.done_host(out_host);
 }
+int sf_step_begin(sf_env *env) {
+  SF_ENV(env);
+  return env->e.step_begin();
+}
+int sf_step_end(sf_env *env, const uint8_t *cmd) {
+  SF_ENV(env);
+  return env->e.step_end_host(cmd);
+}
+int sf_step_end_device(sf_env *env, const uint8_t *d_cmd) {
+  SF_ENV(env);
+  return env->e.step_end_device(d_cmd);
+}
+int sf_agent_alive(sf_env *env, uint8_t *out_host) {
+  SF_ENV(env);
+  return env->e.agent_alive_host(out_host);
+}
+int sf_agent_alive_device(sf_env *env, uint8_t *d_out) {
+  SF_ENV(env);
+  return env->e.agent_alive_device(d_out);
+}
 int sf_state_digest(sf_env *env, uint64_t *out_host) {
   SF_ENV(env);
   return env->e.state_digest(out_host);
@@ -732,13 +803,30 @@ int sf_comm_init(sf_env *env, const uint8_t *id, int32_t rank, int32_t world) {
   rc = c.nccl(c.init_rank(&c.comm, world, uid, rank), "ncclCommInitRank");
   if (rc) return rc;
   c.world = world, c.rank = rank;
-  SF_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+  // a failure from here on leaves no half-built communicator behind: a retry starts from scratch
+  bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess;
   const size_t bytes = (size_t)env->e.p.A * env->e.p.n_agents * 8 * sizeof(int32_t);
-  for (int j = 0; j < 2; ++j) {
-    SF_HIP(hipEventCreateWithFlags(&c.ready[j], hipEventDisableTiming));
-    SF_HIP(hipEventCreateWithFlags(&c.done[j], hipEventDisableTiming));
-    SF_HIP(hipMalloc((void **)&c.staging[j], bytes));
+  for (int j = 0; j < 2 && ok; ++j)
+    ok = hipEventCreateWithFlags(&c.ready[j], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c.done[j], hipEventDisableTiming) == hipSuccess &&
+         hipMalloc((void **)&c.staging[j], bytes) == hipSuccess;
+  if (!ok) {
+    c.shutdown();
+    c.used[0] = c.used[1] = false, c.issued = 0;
+    return sf::fail(SF_ERR_DEVICE, "sf_comm_init: stream / event / staging allocation failed");
   }
+  return SF_OK;
+}
+int sf_comm_ranks(sf_env *env, int32_t *ranks) {
+  SF_ENV(env);
+  sf::Comm &c = env->comm;
+  if (!ranks) return sf::fail(SF_ERR_ARG, "null output");
+  if (!c.comm) return sf::fail(SF_ERR_ARG, "sf_comm_init has not been called");
+  if (!c.count_fn) return sf::fail(SF_ERR_DEVICE, "RCCL lacks ncclCommCount");
+  int n = 0;
+  int rc = c.nccl(c.count_fn(c.comm, &n), "ncclCommCount");
+  if (rc) return rc;
+  *ranks = n;
   return SF_OK;
 }
 int sf_results_allgather(sf_env *env, int32_t *d_out) {
@@ -746,6 +834,8 @@ int sf_results_allgather(sf_env *env, int32_t *d_out) {
   sf::Comm &c = env->comm;
   if (!c.comm) return sf::fail(SF_ERR_ARG, "sf_comm_init has not been called");
   if (!d_out) return sf::fail(SF_ERR_ARG, "null gather buffer");
+  if (!env->e.was_reset) return sf::fail(SF_ERR_ARG, "sf_reset has not been called");
+  SF_HIP(hipSetDevice(env->e.rt.device));
   hipStream_t st = env->e.rt.stream;
   const size_t count = (size_t)env->e.p.A * env->e.p.n_agents * 8;
   const int j = (int)(c.issued++ & 1u);
@@ -765,6 +855,7 @@ int sf_comm_wait(sf_env *env, int32_t host_too) {
   SF_ENV(env);
   sf::Comm &c = env->comm;
   if (!c.comm) return sf::fail(SF_ERR_ARG, "sf_comm_init has not been called");
+  SF_HIP(hipSetDevice(env->e.rt.device));
   for (int j = 0; j < 2; ++j)
     if (c.used[j]) SF_HIP(hipStreamWaitEvent(env->e.rt.stream, c.done[j], 0));
   if (host_too) SF_HIP(hipStreamSynchronize(c.side));

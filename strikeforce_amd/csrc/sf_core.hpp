@@ -1443,11 +1443,15 @@ struct Core {
   }
 
   // One iteration of the loop body G:1452-1471 followed by the next loop top.
+  // PHASE 0: all of it (the throughput path).  PHASE 1 / 2: the iteration cut where the reference queries the agents of
+  // humans other than `ind` (get_command inside human_action, G:988-999): 1 = zombie_action ... the first update_bull
+  // (G:1455-1463), 2 = human_action ... the second update_bull and the next loop top (G:1464-1471,1444-1450).
+  template <int PHASE = 0>
   static SF_DEV void step(Arena &S, uint8_t *lds, const Params &p, int a) {
     if (S.done) return;
     // the two half-ticks share `update_tmp; hit_human; hit_zombie; ++frame; update_bull` (G:1457-1463,1465-1471)
     SF_STAMP(S, 0);
-    SF_NOUNROLL for (int half = 0; half < 2; ++half) {
+    SF_NOUNROLL for (int half = (PHASE == 2 ? 1 : 0); half < (PHASE == 1 ? 1 : 2); ++half) {
       if (half == 0) {
         zombie_action(S, lds, p);
         SF_STAMP(S, 1);
@@ -1469,6 +1473,7 @@ struct Core {
       update_bull(S, lds, p);
       SF_STAMP(S, 7);
     }
+    if (PHASE == 1) return;
     ++S.steps;
     // the loop top; when the episode ends and auto_reset is on, once more for the episode that begins
     SF_NOUNROLL for (int pass = 0; pass < 2; ++pass) {
@@ -1646,6 +1651,26 @@ struct Core {
       const uint8_t *c = cmds + ((size_t)s * (size_t)p.A + (size_t)a) * (size_t)p.n_agents;
       S.hcmd = W::select(ag, W::gload_u8(c, W::lane(), ag), V((uint32_t)'+'));
       step(S, lds, p, a);
+    }
+    SF_STAMP_END(S, a);
+    store(S, lds, p, a);
+  }
+
+  // One half of one iteration (sf_step_begin / sf_step_end); cmds: [A][n_agents], read by the second half only.
+  static SF_DEV void step_half_body(uint8_t *lds, const Params &p, int a, const uint8_t *cmds, int phase) {
+    Arena S;
+    lds = tables(S, lds, p, a);
+    load(S, lds, p, a);
+    S.wrate = 4u;
+    S.ended = 0;
+    SF_STAMP_BEGIN(S);
+    if (phase == 1) {
+      S.hcmd = V((uint32_t)'+');  // (nothing reads a command before human_action)
+      step<1>(S, lds, p, a);
+    } else {
+      const P ag = W::ltu(W::lane(), (uint32_t)p.n_agents);
+      S.hcmd = W::select(ag, W::gload_u8(cmds + (size_t)a * (size_t)p.n_agents, W::lane(), ag), V((uint32_t)'+'));
+      step<2>(S, lds, p, a);
     }
     SF_STAMP_END(S, a);
     store(S, lds, p, a);

@@ -179,6 +179,7 @@ struct Env {
   Tables tab;
   int NB = 1, cells = 0;
   bool was_reset = false;
+  bool mid_step = false;  // between sf_step_begin and sf_step_end
   RT rt;
   // device buffers
   Tables *d_tab = nullptr;
@@ -352,19 +353,59 @@ struct Env {
     int rc = rt.launch_reset(p, NB, d_tb, d_serial);
     if (rc) return rc;
     was_reset = true;
+    mid_step = false;
     return rt.sync();
   }
 
   int step_host(const uint8_t *cmd) {
     if (!cmd) return fail(SF_ERR_ARG, "null command array");
     if (!was_reset) return fail(SF_ERR_STATE, "sf_step before sf_reset");
+    if (mid_step) return fail(SF_ERR_STATE, "sf_step between sf_step_begin and sf_step_end");
     rt.h2d(d_cmd, cmd, (size_t)p.A * p.n_agents);
     return rt.launch_step(p, NB, d_cmd, 1);
   }
   int step_device(const uint8_t *d_cmds, int k) {
     if (!d_cmds || k < 1) return fail(SF_ERR_ARG, "bad command buffer / step count");
     if (!was_reset) return fail(SF_ERR_STATE, "sf_step_device before sf_reset");
+    if (mid_step) return fail(SF_ERR_STATE, "sf_step_device between sf_step_begin and sf_step_end");
     return rt.launch_step(p, NB, d_cmds, k);
+  }
+  // the iteration in two halves (the reference queries the agents of humans other than `ind` between them, G:988-999)
+  int step_begin() {
+    if (!was_reset) return fail(SF_ERR_STATE, "sf_step_begin before sf_reset");
+    if (mid_step) return fail(SF_ERR_STATE, "sf_step_begin twice without sf_step_end");
+    int rc = rt.launch_step_half(p, NB, d_cmd, 1);
+    if (rc) return rc;
+    mid_step = true;
+    return SF_OK;
+  }
+  int step_end_device(const uint8_t *d_cmds) {
+    if (!d_cmds) return fail(SF_ERR_ARG, "null command array");
+    if (!mid_step) return fail(SF_ERR_STATE, "sf_step_end without sf_step_begin");
+    int rc = rt.launch_step_half(p, NB, d_cmds, 2);
+    if (rc) return rc;
+    mid_step = false;
+    return SF_OK;
+  }
+  int step_end_host(const uint8_t *cmd) {
+    if (!cmd) return fail(SF_ERR_ARG, "null command array");
+    if (!mid_step) return fail(SF_ERR_STATE, "sf_step_end without sf_step_begin");
+    rt.h2d(d_cmd, cmd, (size_t)p.A * p.n_agents);
+    return step_end_device(d_cmd);
+  }
+  int agent_alive_device(uint8_t *d_out) {
+    if (!d_out) return fail(SF_ERR_ARG, "null output buffer");
+    if (!was_reset) return fail(SF_ERR_STATE, "sf_agent_alive before sf_reset");
+    return rt.launch_agent_alive(p, d_out);
+  }
+  int agent_alive_host(uint8_t *out) {
+    if (!out) return fail(SF_ERR_ARG, "null output buffer");
+    if (!was_reset) return fail(SF_ERR_STATE, "sf_agent_alive before sf_reset");
+    // (d_cmd is free between calls: every step entry point uploads or receives its commands anew)
+    int rc = rt.launch_agent_alive(p, d_cmd);
+    if (rc) return rc;
+    rt.d2h(out, d_cmd, (size_t)p.A * p.n_agents);
+    return rt.sync();
   }
 
   int observe_device(float *d_out) {

@@ -55,7 +55,11 @@ def load_library():
         L.sf_comm_init.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
         L.sf_results_allgather.argtypes = [vp, vp]
         L.sf_comm_wait.argtypes = [vp, C.c_int32]
-        for n in ("sf_comm_unique_id", "sf_comm_init", "sf_results_allgather", "sf_comm_wait"):
+        L.sf_comm_ranks.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.sf_step_end_device.argtypes = [vp, vp]
+        L.sf_agent_alive_device.argtypes = [vp, vp]
+        for n in ("sf_comm_unique_id", "sf_comm_init", "sf_results_allgather", "sf_comm_wait", "sf_comm_ranks",
+                  "sf_step_end_device", "sf_agent_alive_device"):
             getattr(L, n).restype = C.c_int
         L.sf_config_defaults.argtypes = [C.POINTER(abi.Config)]
         L.sf_config_defaults.restype = None
@@ -71,7 +75,8 @@ def load_library():
 EXPORTS = ["sf_create", "sf_destroy", "sf_config_defaults", "sf_reset", "sf_step", "sf_step_device", "sf_observe",
            "sf_observe_device", "sf_observe_device_delta", "sf_observe_sparse_device", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
            "sf_set_stream", "sf_synchronize", "sf_kernel_time", "sf_last_error", "sf_abi_version",
-           "sf_comm_unique_id", "sf_comm_init", "sf_results_allgather", "sf_comm_wait"]
+           "sf_comm_unique_id", "sf_comm_init", "sf_results_allgather", "sf_comm_wait", "sf_comm_ranks",
+           "sf_step_begin", "sf_step_end", "sf_step_end_device", "sf_agent_alive", "sf_agent_alive_device"]
 
 
 class ArenaBatch:
@@ -122,6 +127,35 @@ class ArenaBatch:
         if cmd.size != self.cfg.arenas * self.cfg.n_agents:
             raise ValueError("cmd must hold arenas * n_agents command chars")
         self._ck(self.L.sf_step(self.h, cmd.ctypes.data_as(C.c_char_p)), "sf_step")
+
+    def step_begin(self):
+        """The first half of one iteration (gameplay.hpp:1455-1463): up to where the reference asks the agents of humans
+        other than `ind` for their command."""
+        self._ck(self.L.sf_step_begin(self.h), "sf_step_begin")
+
+    def step_end(self, cmd):
+        """The second half (gameplay.hpp:1464-1471) and the next loop top; cmd as for step()."""
+        cmd = np.ascontiguousarray(cmd, dtype=np.uint8)
+        if cmd.size != self.cfg.arenas * self.cfg.n_agents:
+            raise ValueError("cmd must hold arenas * n_agents command chars")
+        self._ck(self.L.sf_step_end(self.h, cmd.ctypes.data_as(C.c_char_p)), "sf_step_end")
+
+    def step_end_device(self, d_cmd_ptr):
+        self._ck(self.L.sf_step_end_device(self.h, C.c_void_p(d_cmd_ptr)), "sf_step_end_device")
+
+    def agent_alive(self):
+        """[arenas][n_agents] uint8: 1 while the commanded human is alive and still has its Agent (Human::active_agent)."""
+        out = np.zeros((self.cfg.arenas, self.cfg.n_agents), dtype=np.uint8)
+        self._ck(self.L.sf_agent_alive(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))), "sf_agent_alive")
+        return out
+
+    def agent_alive_device(self, d_out_ptr):
+        self._ck(self.L.sf_agent_alive_device(self.h, C.c_void_p(d_out_ptr)), "sf_agent_alive_device")
+
+    def comm_ranks(self):
+        n = C.c_int32(0)
+        self._ck(self.L.sf_comm_ranks(self.h, C.byref(n)), "sf_comm_ranks")
+        return int(n.value)
 
     def step_device(self, d_cmd_ptr, k):
         """k loop iterations in one launch; d_cmd_ptr: device address of uint8 [k][arenas][n_agents]."""

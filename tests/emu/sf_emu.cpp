@@ -41,6 +41,19 @@ static void run_step(const Params &p, const uint8_t *cmds, int k) {
   }
 }
 
+template <int NB>
+static void run_step_half(const Params &p, const uint8_t *cmds, int phase) {
+  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab));
+  for (int a = 0; a < p.A; ++a) {
+    if (!hbm_plane(p.cells_pad))
+      Core<WaveEmu, NB, false, true>::step_half_body(lds.data(), p, a, cmds, phase);
+    else if (use_bitmaps(p.cells_pad))
+      Core<WaveEmu, NB, true, true>::step_half_body(lds.data(), p, a, cmds, phase);
+    else
+      Core<WaveEmu, NB, true, false>::step_half_body(lds.data(), p, a, cmds, phase);
+  }
+}
+
 static void run_observe(const Params &p, float *out) {
   const int W2 = SF_OBS_WINDOW * SF_OBS_WINDOW;
   std::vector<uint32_t> occ(W2);
@@ -120,6 +133,23 @@ struct CpuRT {
     }
     return SF_OK;
   }
+  int launch_step_half(const Params &p, int NB, const uint8_t *cmds, int phase) {
+    switch (NB) {
+      case 1: run_step_half<1>(p, cmds, phase); break;
+      case 2: run_step_half<2>(p, cmds, phase); break;
+      case 3: run_step_half<3>(p, cmds, phase); break;
+      default: run_step_half<4>(p, cmds, phase); break;
+    }
+    return SF_OK;
+  }
+  int launch_agent_alive(const Params &p, uint8_t *out) {
+    for (int i = 0; i < p.A * p.n_agents; ++i) {
+      const int a = i / p.n_agents, g = i % p.n_agents;
+      const uint32_t fl = p.hum[((size_t)HW_FLAGS * (size_t)p.A + (size_t)a) * (size_t)p.H + (size_t)g];
+      out[i] = (uint8_t)((fl & (HF_ALIVE | HF_CTRL)) == (HF_ALIVE | HF_CTRL));
+    }
+    return SF_OK;
+  }
   int launch_done(const Params &p, uint8_t *out) {
     for (int i = 0; i < p.A * p.n_agents; ++i) {
       const int32_t *sc = p.scal + (size_t)(i / p.n_agents) * SC_WORDS;
@@ -176,6 +206,9 @@ int sfe_destroy(sfe_env *env) {
 int sfe_reset(sfe_env *env, const uint64_t *tb, const uint64_t *serial) { return env->e.reset(tb, serial); }
 int sfe_step(sfe_env *env, const uint8_t *cmd) { return env->e.step_host(cmd); }
 int sfe_step_many(sfe_env *env, const uint8_t *cmds, int32_t k) { return env->e.step_device(cmds, k); }
+int sfe_step_begin(sfe_env *env) { return env->e.step_begin(); }
+int sfe_step_end(sfe_env *env, const uint8_t *cmd) { return env->e.step_end_host(cmd); }
+int sfe_agent_alive(sfe_env *env, uint8_t *out) { return env->e.agent_alive_host(out); }
 int sfe_observe(sfe_env *env, float *out) { return env->e.observe_host(out); }
 int sfe_results(sfe_env *env, int32_t *out) { return env->e.results_host(out); }
 int sfe_done(sfe_env *env, uint8_t *out) { return env->e.done_host(out); }

@@ -135,6 +135,19 @@ class Oracle:
         k = cmds.shape[0]
         self.L.sfo_step_many(self.h, cmds.ctypes.data_as(C.c_char_p), k)
 
+    def step_begin(self):
+        assert self.L.sfo_step_begin(self.h) == 0
+
+    def step_end(self, cmd):
+        cmd = np.ascontiguousarray(cmd, dtype=np.uint8)
+        assert cmd.size == self.cfg.arenas * self.cfg.n_agents
+        assert self.L.sfo_step_end(self.h, cmd.ctypes.data_as(C.c_char_p)) == 0
+
+    def agent_alive(self):
+        out = np.zeros((self.cfg.arenas, self.cfg.n_agents), dtype=np.uint8)
+        assert self.L.sfo_agent_alive(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+        return out
+
     def observe(self):
         out = np.empty((self.cfg.arenas, self.cfg.n_agents, abi.OBS_CHANNELS, abi.OBS_WINDOW, abi.OBS_WINDOW),
                        dtype=np.float32)

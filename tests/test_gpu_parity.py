@@ -168,3 +168,38 @@ def test_delta_observation_equals_full_observation(name, arenas, steps):
     g.observe_device(full.data_ptr())
     g.synchronize()
     assert torch.equal(keep.view(torch.int32), full.view(torch.int32))
+
+
+@pytest.mark.parametrize("name,steps,k", [("C3", 100, 50), ("C4", 60, 30), ("C5", 40, 20)])
+def test_full_size_digest_parity_4096_arenas(name, steps, k):
+    """BASELINE.json configs[2..4] at the size bench.py reports them (4096 arenas on one GPU: for configs[3] and [4]
+    that is the per-GPU shard of the 32768-arena configuration, flag planes and `aux_dmg` in HBM): every arena's
+    digest after `steps` steps in launches of `k` against the oracle, which runs the same arenas 256 at a time
+    (arenas are independent; the oracle's pointer grid for 4096 arenas of 256x256 would be 15 GB), and the structural
+    invariants on five arenas spread over the arena-stride range."""
+    from test_invariants import check
+    A, chunk = 4096, 256
+    w = config.baseline_workload(name, arenas=A)
+    n = w.cfg.n_agents
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    cmds, _ = config.bench_commands(A, n, steps)
+    d = _dev_cmds(cmds)
+    for s in range(0, steps, k):
+        g.step_device(d.data_ptr() + s * A * n, min(k, steps - s))
+    g.synchronize()
+    got = g.digest()
+    done_g = g.done()
+    for first in range(0, A, chunk):
+        wc = config.baseline_workload(name, arenas=chunk)
+        wc.cfg.reseed_stride = A  # an arena that restarts takes the seed the 4096-arena run gives it
+        o = Oracle(wc)
+        o.reset(*wc.seeds(first_arena=first))
+        o.step_many(cmds[:, first:first + chunk])
+        want = o.digest()
+        bad = np.nonzero(want != got[first:first + chunk])[0]
+        assert bad.size == 0, "%s: arenas %s differ from the oracle" % (name, (bad[:8] + first).tolist())
+        o.close()
+    for a in (0, 1, 777, 2048, 4095):
+        check(_gpu_dump(g, a), w.cfg)
+    assert done_g.shape == (A,)
