@@ -223,6 +223,12 @@ int sf_observe_device_delta(sf_env *env, float *d_out);
  * take the dense call for this step.  An observation of the BASELINE configurations has ~250 non-zeros. */
 #define SF_OBS_POV_FLOATS 160
 int sf_observe_sparse_device(sf_env *env, uint32_t *d_keys, float *d_vals, uint32_t *d_counts, float *d_pov, int32_t cap);
+/* The dense call for exactly the agents whose list did not fit (d_counts[i] > cap, or the 0xffffffff marker), to be
+ * issued right behind sf_observe_sparse_device with the same d_counts / cap: their rows of d_dense
+ * ([arenas][n_agents][32][31][31], the other rows are not touched) get the observation sf_observe_device would write,
+ * and their rows of d_pov are rewritten from it.  Normally no agent qualifies and the two launches exit at once; no
+ * host synchronisation either way.  sf_policy_forward_sparse_or_dense then evaluates those agents from d_dense. */
+int sf_observe_overflow_device(sf_env *env, const uint32_t *d_counts, int32_t cap, float *d_dense, float *d_pov);
 
 /* Per (arena, agent) 8 x int32: kills, teams_kills, loot, damage, effect, Hp, frames, outcome
  * (gameplay.hpp:461,588-593,625-629; Character.hpp:294).  Latched at episode end. */

@@ -78,6 +78,13 @@ int sf_policy_forward(sf_policy *p, const float *d_obs, int32_t agents, float *d
  * clears) that count — non-zero means the caller should have taken the dense pair of calls for that step. */
 int sf_policy_forward_sparse(sf_policy *p, const uint32_t *d_keys, const float *d_vals, const uint32_t *d_counts,
                              const float *d_pov, int32_t cap, int32_t agents, float *d_probs, float *d_value);
+/* The same with a dense fallback, so that no agent is ever evaluated on a blank window: the agents whose list did not
+ * fit are redone from their rows of d_dense (what sf_observe_overflow_device wrote: [agents][32][31][31]; the other rows
+ * are never read) by a second conv0 launch that is idle when every list fitted.  Results equal the dense pair of calls
+ * bit for bit for every agent; nothing is counted in sf_policy_sparse_overflows. */
+int sf_policy_forward_sparse_or_dense(sf_policy *p, const uint32_t *d_keys, const float *d_vals, const uint32_t *d_counts,
+                                      const float *d_pov, int32_t cap, int32_t agents, const float *d_dense,
+                                      float *d_probs, float *d_value);
 int sf_policy_sparse_overflows(sf_policy *p, int32_t *count);
 
 /* The tail of Agent::predict() + Agent::update() (Agent.hpp:200-222): v[0] = 0.5, v[i>0] *= 0.5/(1-v[0]+1e-5),
@@ -104,6 +111,10 @@ int sf_policy_kernel_time(sf_policy *p, int32_t enable, float *ms, double *flop,
  * kernel (k_gemm_b3: conv1 / conv2 at M >= 16 384).  flop[] is the algorithmic 2*M*N*K in both; the split kernel
  * executes six bf16 products per algorithmic one. */
 int sf_policy_kernel_time_ex(sf_policy *p, int32_t enable, float ms[2], double flop[2], int32_t launches[2]);
+/* The same by kernel: 0 k_gemm (f32 MFMA) + fix-ups, 1 k_gemm_b3 (conv1 / conv2 on the bf16 pipe), 2 conv0 on the
+ * non-zeros (list form; flop[2] = 0: the useful work depends on the lists, 2 * 160 * sum over non-zeros of the output
+ * pixels they reach), 3 k_tail (conv3 + GRU cells + combined_processor + heads). */
+int sf_policy_kernel_time_by_kernel(sf_policy *p, int32_t enable, float ms[4], double flop[4], int32_t launches[4]);
 
 /* The matrix kernel on its own, for unit tests and roofline measurements: C[M][ldc] = A[M][lda] * W[N][K]^T + bias
  * (bias may be NULL), all device pointers, f32; K % 32 == 0, N % 160 == 0, lda % 4 == 0.  Every Linear / GRU gate

@@ -111,6 +111,7 @@ DIMS_LINE = ("gameplay.hpp", 37)
 
 
 NATIVE_DIMS = (3, 30, 100, 9000, 9000, 9000, 9000)
+BENCH_DIMS = (1, 64, 64, 8, 24, 64, 9000)  # BASELINE.json configs[2]: 64x64, H8 Z24 B64 (bench.py cpu_baseline, kind "reference")
 
 
 def binary_for(dims=None, squad_agents=False):
@@ -195,4 +196,5 @@ if __name__ == "__main__":
         build(a.ref, a.quiet, [int(x) for x in a.dims.split(",")] if a.dims else None, a.squad_agents)
         if not a.dims and not a.squad_agents:  # the default call (oracle/Makefile `ref`) also makes the Squad-agents flavour
             build(a.ref, a.quiet, None, True)
+            build(a.ref, a.quiet, BENCH_DIMS)  # and the one bench.py times as its cpu_baseline (BASELINE configs[2])
     sys.exit(0)

@@ -19,7 +19,11 @@
 //   calls                           predict/update calls since the last `calls`
 //   obs <agent id>                  the observation that agent's last predict() received (30752 hex words)
 //   observe <slot>                  Custom.hpp's window encoding for hum[slot] now (through a probe agent)
+//   bench <steps> <seed>            timing (bench.py's cpu_baseline): `steps` iterations under the 28-command random agent
+//                                   of SURVEY §8d (LCG x <- 1664525 x + 1013904223, command (x >> 16) % 28); when the
+//                                   player is dead the game is set up again with tb + 1 (check_end is not in the build)
 //   quit
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -64,7 +68,7 @@ std::map<int, char> script;        // agent id -> the command char it will answe
 int next_id = 0, live_agents = 0;
 bool probing = false;
 std::vector<float> probe_obs;
-long long steps = 0;
+long long steps = 0, bench_tb = 0, bench_serial = 0;
 }  // namespace
 
 Agent::Agent() : id(probing ? -1 : next_id++) {
@@ -239,6 +243,7 @@ int main() {
             g.chest = 0;  // gameplay.hpp:1234 does not reset it: every reset here is a first game
             g.setup();    // gameplay.hpp:1231-1277 -> load_data() :1741-1925
             g.manual = !agents;  // load_data leaves `manual = true` for the keyboard toggle ('3'); agents mode = automate
+            bench_tb = tb, bench_serial = serial;
             Environment::Random::_srand(tb, serial);  // the explicit seed replaces time()/libc rand, gameplay.hpp:1233,1745-1747
             steps = 0;
             ++g.frame;   // gameplay.hpp:1441
@@ -272,6 +277,28 @@ int main() {
             if (!had) h.reset_agent_active();
             probing = false;
             print_obs(probe_obs);
+        } else if (s.rfind("bench ", 0) == 0) {
+            long long n = 0, done_steps = 0, resets = 0;
+            unsigned x = 0;
+            sscanf(s.c_str() + 6, "%lld %u", &n, &x);
+            static const char table[] = "+qeuzxawsdfghjkl;'cvbnm,./[]";
+            long long tb = bench_tb;
+            auto t0 = std::chrono::steady_clock::now();
+            for (; done_steps < n; ++done_steps) {
+                if (hum[ind].get_Hp() <= 0 || !mh[ind]) {  // "You Died": play() returns, the next game starts
+                    g.chest = 0;
+                    g.setup();
+                    Environment::Random::_srand(++tb, bench_serial);
+                    ++g.frame;
+                    loop_top();
+                    ++resets;
+                }
+                x = x * 1664525u + 1013904223u;
+                one_step(std::string(1, table[(x >> 16) % 28]));
+            }
+            double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            bench_tb = tb;
+            printf("ok %lld %.6f %lld\n", done_steps, sec, resets);
         } else if (s == "quit") {
             break;
         } else {

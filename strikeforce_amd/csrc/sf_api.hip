@@ -60,6 +60,19 @@ __global__ void k_agent_alive(Params p, uint8_t *out) {
   gptr(out)[i] = (uint8_t)((fl & (HF_ALIVE | HF_CTRL)) == (HF_ALIVE | HF_CTRL));
 }
 
+// sf_observe_overflow_device, second step: the 160 centre values of the agents whose list did not fit, from the dense
+// observation k_observe (mode 4) has just written for them (a crowded window's records do not cover every cell)
+__global__ void k_pov_from_dense(const uint32_t *counts, int cap, const float *dense, float *pov, int agents) {
+  const int i = (int)blockIdx.x;
+  const uint32_t c = gptr(counts)[i];
+  if (i >= agents || !(c == 0xffffffffu || c > (uint32_t)cap)) return;
+  const int t = (int)threadIdx.x;  // 160 threads: cell = t >> 5 of (-1,0) (0,-1) (0,0) (0,1) (1,0), channel = t & 31
+  const int cell = t >> 5, ch = t & 31;
+  const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0, dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
+  const int w = (SF_OBS_WINDOW / 2 + dy) * SF_OBS_WINDOW + (SF_OBS_WINDOW / 2 + dx);
+  gptr(pov)[(size_t)i * (5 * SF_OBS_CHANNELS) + t] = gptr(dense)[(size_t)i * SF_OBS_FLOATS + (size_t)ch * (SF_OBS_WINDOW * SF_OBS_WINDOW) + w];
+}
+
 // check_end()'s verdict per (arena, agent) on the device (sf_done_device)
 __global__ void k_done(Params p, uint8_t *out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -151,6 +164,11 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   const uint32_t hf = gptr(p.hum)[((size_t)HW_FLAGS * p.A + a) * p.H + g];
   const uint32_t center = gptr(p.hum)[((size_t)HW_POS * p.A + a) * p.H + g];
   SF_GLOBAL uint32_t *old = nzprev ? gptr(nzprev) + (size_t)blockIdx.x * OBS_W2 : nullptr;
+  if (mode == 4) {  // sf_observe_overflow_device: the plain dense write, but only for the agents whose list did not fit
+    const uint32_t c = gptr(sp.counts)[blockIdx.x];
+    if (!(c == 0xffffffffu || c > (uint32_t)sp.cap)) return;  // (uniform over the workgroup)
+    mode = 0;
+  }
   if (mode == 3 && (hf & (HF_ALIVE | HF_CTRL)) != (HF_ALIVE | HF_CTRL)) {  // no observer: an empty list
     if (tid == 0) gptr(sp.counts)[blockIdx.x] = 0u;
     if (tid < 5 * SF_OBS_CHANNELS) gptr(sp.pov)[(size_t)blockIdx.x * (5 * SF_OBS_CHANNELS) + tid] = 0.f;
@@ -587,6 +605,20 @@ struct HipRT {
     return SF_OK;
   }
 
+  int launch_observe_overflow(const Params &p, const uint32_t *counts, int cap, float *dense, float *pov) {
+    SF_HIP(hipSetDevice(device));
+    const int n = p.A * p.n_agents;
+    hipLaunchKernelGGL(k_observe, dim3((unsigned)n), dim3(OBS_THREADS),
+                       (size_t)(HW_WORDS * p.H + ZW_WORDS * p.Z + BW_WORDS * p.B) * sizeof(uint32_t) + sizeof(int32_t) * 12 +
+                           sizeof(Derived) * (size_t)(p.npc_block + 1),
+                       stream, p, dense, (uint32_t *)nullptr, 4,
+                       ObsSparse{nullptr, nullptr, const_cast<uint32_t *>(counts), nullptr, cap});
+    SF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_pov_from_dense, dim3((unsigned)n), dim3(5 * SF_OBS_CHANNELS), 0, stream, counts, cap, dense, pov, n);
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+  }
+
   int kernel_time(int enable, float *ms, int *launches) {
     SF_HIP(hipStreamSynchronize(stream));
     float total = 0.f;
@@ -723,6 +755,10 @@ int sf_observe_device_delta(sf_env *env, float *d_out) {
 int sf_observe_device(sf_env *env, float *d_out) {
   SF_ENV(env);
   return env->e.observe_device(d_out);
+}
+int sf_observe_overflow_device(sf_env *env, const uint32_t *d_counts, int32_t cap, float *d_dense, float *d_pov) {
+  SF_ENV(env);
+  return env->e.observe_overflow_device(d_counts, cap, d_dense, d_pov);
 }
 int sf_observe_sparse_device(sf_env *env, uint32_t *d_keys, float *d_vals, uint32_t *d_counts, float *d_pov, int32_t cap) {
   SF_ENV(env);

@@ -420,6 +420,13 @@ struct Env {
     if (!was_reset) return fail(SF_ERR_STATE, "sf_observe before sf_reset");
     return rt.launch_observe_sparse(p, d_keys, d_vals, d_counts, d_pov, cap);
   }
+  int observe_overflow_device(const uint32_t *d_counts, int cap, float *d_dense, float *d_pov) {
+    if (!d_counts || !d_dense || !d_pov) return fail(SF_ERR_ARG, "null buffer");
+    if (cap < 1) return fail(SF_ERR_ARG, "sf_observe_overflow_device: cap must be positive");
+    if (!was_reset) return fail(SF_ERR_STATE, "sf_observe before sf_reset");
+    if (d_dense == delta_ptr) delta_ptr = nullptr;
+    return rt.launch_observe_overflow(p, d_counts, cap, d_dense, d_pov);
+  }
   int observe_device_delta(float *d_out) {
     if (!d_out) return fail(SF_ERR_ARG, "null observation buffer");
     if (!was_reset) return fail(SF_ERR_STATE, "sf_observe before sf_reset");

@@ -740,9 +740,9 @@ __global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const f
     float pvv[EPT];
     auto fetch = [&](int b) {
       pn = li.counts[b];
-      if (pn > (uint32_t)C0_LCAP || pn > (uint32_t)li.cap) {
+      if (pn > (uint32_t)C0_LCAP || pn > (uint32_t)li.cap) {  // (the 0xffffffff marker of a crowded window too)
         pn = 0u;
-        if (t == 0) atomicAdd(li.overflows, 1u);
+        if (t == 0 && li.overflows) atomicAdd(li.overflows, 1u);  // null: a dense fallback launch redoes this agent
       }
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
@@ -786,8 +786,18 @@ __global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const f
       if (i < NV) pre[k] = __builtin_nontemporal_load(src + i);
     }
   };
-  if ((int)blockIdx.x < agents) request((int)blockIdx.x);
-  for (int b = (int)blockIdx.x; b < agents; b += (int)gridDim.x) {
+  // li.counts given (the fallback launch behind a list-form forward): only the agents whose list did not fit — count
+  // beyond cap or the kernel's list, or the crowded-window marker — are redone from the dense buffer; the others keep
+  // what the list launch wrote.  nxt(b): the first such agent among b, b + gridDim.x, ... (uniform over the workgroup)
+  auto nxt = [&](int b) {
+    if (li.counts)
+      while (b < agents && !(li.counts[b] > (uint32_t)C0_LCAP || li.counts[b] > (uint32_t)li.cap)) b += (int)gridDim.x;
+    return b;
+  };
+  int bnext = nxt((int)blockIdx.x);
+  if (bnext < agents) request(bnext);
+  for (int b = bnext; b < agents; b = bnext) {
+  bnext = nxt(b + (int)gridDim.x);
   for (int i = t; i < C0_ACC / 4; i += C0_T) reinterpret_cast<f32x4 *>(acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   uint32_t count = 0;  // list length, the same value in every thread
@@ -852,7 +862,7 @@ __global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const f
       if (k >= ks && k < ke) append(k, (mpack >> (2 * k)) & 3u, offs[k * C0_WAVES + w] - base + lanepre[k]);
     count = offs[ke * C0_WAVES] - base;
     __syncthreads();
-    if (ke == NIT && b + (int)gridDim.x < agents) request(b + (int)gridDim.x);  // `pre` is free: fetch the next agent
+    if (ke == NIT && bnext < agents) request(bnext);  // `pre` is free: fetch the next agent
     process(count);
     __syncthreads();
     ks = ke;
@@ -1352,9 +1362,9 @@ struct Policy {
   // timing of the GEMM launches
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-  std::vector<char> event_split;  // per event: the launch went to the bf16-split kernel
+  std::vector<char> event_split;  // per event: 0 k_gemm (f32 MFMA), 1 k_gemm_b3 (bf16 split), 2 conv0 on the non-zeros, 3 k_tail
   size_t used_events = 0;
-  double flop = 0, flop_split = 0;
+  double flop = 0, flop_split = 0, flop_kind[4] = {0, 0, 0, 0};
 
   ~Policy() {
     for (void *p : owned) (void)hipFree(p);
@@ -1414,7 +1424,7 @@ struct Policy {
     else launch_t<1, 5, 32, MODE>(g);
   }
   // timing of one matrix launch: records the start event, returns the end event to record behind the launch
-  int time_begin(double fl, bool split, hipEvent_t *e1) {
+  int time_begin(double fl, bool split, hipEvent_t *e1, int kind = -1) {
     *e1 = nullptr;
     if (!timing) return SF_OK;
     if (used_events == events.size()) {
@@ -1426,9 +1436,11 @@ struct Policy {
     }
     const hipEvent_t e0 = events[used_events].first;
     *e1 = events[used_events].second;
-    event_split[used_events] = split ? 1 : 0;
+    if (kind < 0) kind = split ? 1 : 0;
+    event_split[used_events] = (char)kind;
     ++used_events;
-    (split ? flop_split : flop) += fl;
+    if (kind != 2) (split ? flop_split : flop) += fl;  // (conv0 on the non-zeros is not a matrix launch: sf_policy_kernel_time leaves it out)
+    flop_kind[kind] += fl;
     SFP_HIP(hipEventRecord(e0, stream));
     return SF_OK;
   }
@@ -1601,6 +1613,8 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
   return sf_policy_reset_memory(*out, nullptr);
 }
 
+// li + d_obs together: list form with a dense fallback for the agents whose list did not fit (d_obs need only be valid
+// for those: sf_observe_overflow_device)
 static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, float *d_value, const C0List *li = nullptr,
                    const float *d_pov = nullptr) {
   int rc = check_agents(p, agents);
@@ -1613,7 +1627,12 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
   // GameCNN                                                                    Modules.hpp:66-71
   const dim3 c0_grid((unsigned)(agents < p->sk_blocks / 2 ? agents : p->sk_blocks / 2));
   if (li) {
+    hipEvent_t e0 = nullptr;
+    if ((rc = p->time_begin(0.0, false, &e0, 2))) return rc;  // useful flop depends on the lists: the caller counts the non-zeros
     hipLaunchKernelGGL(k_conv0_sparse<true>, c0_grid, dim3(C0_T), C0_LDS, st, (const float *)nullptr, p->conv0_wt, p->act[0], agents, *li);
+    if (e0) SFP_HIP(hipEventRecord(e0, st));
+    if (d_obs)  // redo the agents whose list did not fit from their dense observation (none, normally: the launch is idle)
+      hipLaunchKernelGGL(k_conv0_sparse<false>, c0_grid, dim3(C0_T), C0_LDS, st, d_obs, p->conv0_wt, p->act[0], agents, *li);
   } else if (p->dense_conv0) {
     if ((rc = p->conv(d_obs, p->conv_w[0], p->act[0], agents, 31, OBS_C, 1))) return rc;
   } else {
@@ -1624,7 +1643,7 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
   if (p->fused_tail) {
     // (timed as one launch on the f32 pipe: conv3 + 4 GRU gate products + combined_processor + 6 ResB layers)
     hipEvent_t e1 = nullptr;
-    if ((rc = p->time_begin(2.0 * agents * ((double)HID * 9 * HID + 4.0 * G3 * HID + (double)HID * COMB_PAD + 6.0 * HID * HID), false, &e1)))
+    if ((rc = p->time_begin(2.0 * agents * ((double)HID * 9 * HID + 4.0 * G3 * HID + (double)HID * COMB_PAD + 6.0 * HID * HID), false, &e1, 3)))
       return rc;
     TailArgs t{};
     t.act2 = p->act[2], t.obs = d_obs, t.pov = d_pov, t.conv3_w = p->conv_w[3];
@@ -1713,6 +1732,16 @@ int sf_policy_forward_sparse(sf_policy *pp, const uint32_t *d_keys, const float 
   if (!d_keys || !d_vals || !d_counts || !d_pov || cap < 1) return sfp::fail(SF_ERR_ARG, "null buffer or cap < 1");
   const sfp::C0List li{d_keys, d_vals, d_counts, cap, p->d_overflows};
   return sfp::forward(p, nullptr, agents, d_probs, d_value, &li, d_pov);
+}
+
+int sf_policy_forward_sparse_or_dense(sf_policy *pp, const uint32_t *d_keys, const float *d_vals, const uint32_t *d_counts,
+                                      const float *d_pov, int32_t cap, int32_t agents, const float *d_dense, float *d_probs,
+                                      float *d_value) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
+  if (!d_keys || !d_vals || !d_counts || !d_pov || !d_dense || cap < 1) return sfp::fail(SF_ERR_ARG, "null buffer or cap < 1");
+  const sfp::C0List li{d_keys, d_vals, d_counts, cap, nullptr};
+  return sfp::forward(p, d_dense, agents, d_probs, d_value, &li, d_pov);
 }
 
 int sf_policy_sparse_overflows(sf_policy *pp, int32_t *count) {
@@ -1818,8 +1847,9 @@ int sf_policy_kernel_time_ex(sf_policy *pp, int32_t enable, float ms[2], double 
   for (size_t i = 0; i < p->used_events; ++i) {
     float t = 0.f;
     SFP_HIP(hipEventElapsedTime(&t, p->events[i].first, p->events[i].second));
-    total[p->event_split[i] ? 1 : 0] += t;
-    ++n[p->event_split[i] ? 1 : 0];
+    if (p->event_split[i] == 2) continue;  // conv0 on the non-zeros: sf_policy_kernel_time_by_kernel
+    total[p->event_split[i] == 1 ? 1 : 0] += t;
+    ++n[p->event_split[i] == 1 ? 1 : 0];
   }
   for (int k = 0; k < 2; ++k) {
     if (ms) ms[k] = total[k];
@@ -1828,6 +1858,26 @@ int sf_policy_kernel_time_ex(sf_policy *pp, int32_t enable, float ms[2], double 
   }
   p->used_events = 0;
   p->flop = p->flop_split = 0;
+  for (double &f : p->flop_kind) f = 0;
+  p->timing = enable != 0;
+  return SF_OK;
+}
+
+int sf_policy_kernel_time_by_kernel(sf_policy *pp, int32_t enable, float ms[4], double flop[4], int32_t launches[4]) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p || !ms || !flop || !launches) return sfp::fail(SF_ERR_ARG, "null argument");
+  SFP_HIP(hipSetDevice(p->device));
+  SFP_HIP(hipStreamSynchronize(p->stream));
+  for (int k = 0; k < 4; ++k) ms[k] = 0.f, flop[k] = p->flop_kind[k], launches[k] = 0;
+  for (size_t i = 0; i < p->used_events; ++i) {
+    float t = 0.f;
+    SFP_HIP(hipEventElapsedTime(&t, p->events[i].first, p->events[i].second));
+    ms[(int)p->event_split[i]] += t;
+    ++launches[(int)p->event_split[i]];
+  }
+  p->used_events = 0;
+  p->flop = p->flop_split = 0;
+  for (double &f : p->flop_kind) f = 0;
   p->timing = enable != 0;
   return SF_OK;
 }

@@ -46,6 +46,8 @@ def load_library():
         L.sf_observe_device.argtypes = [vp, vp]
         L.sf_observe_device_delta.argtypes = [vp, vp]
         L.sf_observe_sparse_device.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
+        L.sf_observe_overflow_device.argtypes = [vp, vp, C.c_int32, vp, vp]
+        L.sf_observe_overflow_device.restype = C.c_int
         L.sf_results_device.argtypes = [vp, vp]
         L.sf_done_device.argtypes = [vp, vp]
         L.sf_set_stream.argtypes = [vp, vp]
@@ -73,7 +75,7 @@ def load_library():
 
 # every symbol include/strikeforce.h declares
 EXPORTS = ["sf_create", "sf_destroy", "sf_config_defaults", "sf_reset", "sf_step", "sf_step_device", "sf_observe",
-           "sf_observe_device", "sf_observe_device_delta", "sf_observe_sparse_device", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
+           "sf_observe_device", "sf_observe_device_delta", "sf_observe_sparse_device", "sf_observe_overflow_device", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
            "sf_set_stream", "sf_synchronize", "sf_kernel_time", "sf_last_error", "sf_abi_version",
            "sf_comm_unique_id", "sf_comm_init", "sf_results_allgather", "sf_comm_wait", "sf_comm_ranks",
            "sf_step_begin", "sf_step_end", "sf_step_end_device", "sf_agent_alive", "sf_agent_alive_device"]
@@ -176,6 +178,12 @@ class ArenaBatch:
         [agents][160] centre values): what PolicyBatch.forward_sparse consumes."""
         self._ck(self.L.sf_observe_sparse_device(self.h, C.c_void_p(d_keys_ptr), C.c_void_p(d_vals_ptr), C.c_void_p(d_counts_ptr),
                                                  C.c_void_p(d_pov_ptr), int(cap)), "sf_observe_sparse_device")
+
+    def observe_overflow_device(self, d_counts_ptr, cap, d_dense_ptr, d_pov_ptr):
+        """Right behind observe_sparse_device, same counts / cap: the dense observation of exactly the agents whose list
+        did not fit, into their rows of d_dense ([agents][32][31][31]); their d_pov rows are rewritten from it."""
+        self._ck(self.L.sf_observe_overflow_device(self.h, C.c_void_p(d_counts_ptr), int(cap), C.c_void_p(d_dense_ptr),
+                                                   C.c_void_p(d_pov_ptr)), "sf_observe_overflow_device")
 
     def observe_device(self, d_out_ptr):
         self._ck(self.L.sf_observe_device(self.h, C.c_void_p(d_out_ptr)), "sf_observe_device")

@@ -113,6 +113,8 @@ def _bind(L):
     L.sf_policy_reset_memory_n.restype = C.c_int
     L.sf_policy_forward.argtypes = [vp, vp, C.c_int32, vp, vp]
     L.sf_policy_forward_sparse.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp]
+    L.sf_policy_forward_sparse_or_dense.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
+    L.sf_policy_kernel_time_by_kernel.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.sf_policy_sparse_overflows.argtypes = [vp, C.POINTER(C.c_int32)]
     L.sf_policy_act.argtypes = [vp, vp, C.c_int32, C.c_char_p, C.c_uint64, C.c_int32, vp, vp]
     L.sf_policy_get_memory.argtypes = [vp, C.c_int32, _FP, _FP]
@@ -131,9 +133,10 @@ def _bind(L):
 
 # every symbol include/strikeforce_policy.h declares
 EXPORTS = ["sf_policy_create", "sf_policy_destroy", "sf_policy_reset_memory", "sf_policy_reset_memory_n", "sf_policy_forward", "sf_policy_forward_sparse",
+           "sf_policy_forward_sparse_or_dense",
            "sf_policy_sparse_overflows", "sf_policy_act",
            "sf_policy_get_memory", "sf_policy_set_memory", "sf_policy_set_stream", "sf_policy_synchronize",
-           "sf_policy_kernel_time", "sf_policy_kernel_time_ex", "sf_policy_gemm", "sf_policy_gemm_split", "sf_policy_abi_version"]
+           "sf_policy_kernel_time", "sf_policy_kernel_time_ex", "sf_policy_kernel_time_by_kernel", "sf_policy_gemm", "sf_policy_gemm_split", "sf_policy_abi_version"]
 
 
 class PolicyBatch:
@@ -208,8 +211,18 @@ class PolicyBatch:
         self._ck(self.L.sf_policy_forward(self.h, C.c_void_p(d_obs_ptr), int(agents), C.c_void_p(d_probs_ptr),
                                           C.c_void_p(d_value_ptr)), "sf_policy_forward")
 
-    def forward_sparse(self, d_keys_ptr, d_vals_ptr, d_counts_ptr, d_pov_ptr, cap, agents, d_probs_ptr, d_value_ptr):
-        """forward() on ArenaBatch.observe_sparse_device's lists: same results, no dense observation in between."""
+    def forward_sparse(self, d_keys_ptr, d_vals_ptr, d_counts_ptr, d_pov_ptr, cap, agents, d_probs_ptr, d_value_ptr,
+                       d_dense_ptr=None):
+        """forward() on ArenaBatch.observe_sparse_device's lists: same results, no dense observation in between.
+        d_dense_ptr: the buffer ArenaBatch.observe_overflow_device filled for the agents whose list did not fit; they are
+        then evaluated from it (never on a blank window).  Without it such agents are evaluated as empty and counted
+        (sparse_overflows)."""
+        if d_dense_ptr is not None:
+            self._ck(self.L.sf_policy_forward_sparse_or_dense(
+                self.h, C.c_void_p(d_keys_ptr), C.c_void_p(d_vals_ptr), C.c_void_p(d_counts_ptr), C.c_void_p(d_pov_ptr),
+                int(cap), int(agents), C.c_void_p(d_dense_ptr), C.c_void_p(d_probs_ptr), C.c_void_p(d_value_ptr)),
+                "sf_policy_forward_sparse_or_dense")
+            return
         self._ck(self.L.sf_policy_forward_sparse(self.h, C.c_void_p(d_keys_ptr), C.c_void_p(d_vals_ptr), C.c_void_p(d_counts_ptr),
                                                  C.c_void_p(d_pov_ptr), int(cap), int(agents), C.c_void_p(d_probs_ptr),
                                                  C.c_void_p(d_value_ptr)), "sf_policy_forward_sparse")
@@ -256,6 +269,12 @@ class PolicyBatch:
         ms, fl, n = (C.c_float * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)()
         self._ck(self.L.sf_policy_kernel_time_ex(self.h, 1 if enable else 0, ms, fl, n), "sf_policy_kernel_time_ex")
         return [(ms[k], fl[k], n[k]) for k in range(2)]
+
+    def kernel_time_by_kernel(self, enable=True):
+        """[(ms, algorithmic flop, launches)] for k_gemm (f32 MFMA), k_gemm_b3 (bf16 split), conv0 on the non-zeros, k_tail."""
+        ms, fl, n = (C.c_float * 4)(), (C.c_double * 4)(), (C.c_int32 * 4)()
+        self._ck(self.L.sf_policy_kernel_time_by_kernel(self.h, 1 if enable else 0, ms, fl, n), "sf_policy_kernel_time_by_kernel")
+        return [(float(ms[k]), float(fl[k]), int(n[k])) for k in range(4)]
 
     def kernel_time(self, enable=True):
         """(ms, flop, launches) of the MFMA GEMM launches since the last call; arms / disarms the timers."""

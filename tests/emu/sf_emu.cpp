@@ -157,6 +157,8 @@ struct CpuRT {
     }
     return SF_OK;
   }
+  int launch_observe_overflow(const Params &, const uint32_t *, int, float *, float *) { return SF_ERR_DEVICE; }  // device-only form
+  int launch_observe_sparse(const Params &, uint32_t *, float *, uint32_t *, float *, int) { return SF_ERR_DEVICE; }
   int launch_observe(const Params &p, int, float *out, uint32_t *, int) {  // (delta mode: same final buffer content)
     run_observe(p, out);
     return SF_OK;

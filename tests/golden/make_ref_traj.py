@@ -81,6 +81,41 @@ def run_case(name):
             "digests": digests, "obs_nonzero": obs}
 
 
+def run_squad_agents(steps=300, every=60):
+    """The reference built with USE_AGENT_IN_SQUAD_NPCS (ten Agents, Squad on the shipped world), scripted with
+    tests/test_squad_agents_example.policy: digests per step, and every `every` steps the observations the reference
+    handed its agents — agent 0's at the loop top, the others' inside human_action (gameplay.hpp:988-999) — plus which
+    humans still had an Agent after the step."""
+    import test_squad_agents_example as X
+    w = ref_cases.native(abi.MODE_SQUAD, 2, ref_cases.RICH, maps="shipped")
+    w.cfg.n_agents = 10
+    o = oracle_lib.Oracle(w)
+    r = reftick.RefTick(w, ref_cases.RICH, agents=True, squad_agents=True)
+    tb, serial = 1700000000, 123456789
+    o.reset((C.c_uint64 * 1)(tb), (C.c_uint64 * 1)(serial))
+    r.reset(tb, serial)
+    digests, obs, alive = [], {}, []
+    for s in range(steps):
+        od, rd = o.dump(0), r.dump()
+        assert reftick.first_difference(rd, reftick.arrays_of(od)) is None
+        digests.append("%016x" % digest_of(rd, od, w.cfg))
+        chars = "".join(X.ACTS[X.policy(g, s)] for g in range(10))
+        o.step(np.frombuffer(chars.encode(), dtype=np.uint8))
+        r.step(chars)
+        asked = sorted({c[0] for c in r.calls() if c[1] == "P"})
+        if s % every == 0:
+            obs[str(s)] = {str(g): sparse(r.last_obs(g)) for g in asked}
+        r.dump()
+        alive.append("".join(str(x) for x in r.active_agents[:10]))
+        if o.done()[0]:
+            break
+    od, rd = o.dump(0), r.dump()
+    digests.append("%016x" % digest_of(rd, od, w.cfg))
+    r.close()
+    return {"tb": tb, "serial": serial, "reference_build": "native, -DUSE_AGENT_IN_SQUAD_NPCS", "digests": digests,
+            "agent_obs_nonzero": obs, "agent_alive_after_step": alive}
+
+
 if __name__ == "__main__":
     if not reftick.available():
         raise SystemExit("oracle/_ref/sf_ref_tick is not built: needs the reference checkout (python oracle/ref_tick.py)")
@@ -90,6 +125,8 @@ if __name__ == "__main__":
     for name in ref_cases.GOLDEN_CASES:
         data["cases"][name] = run_case(name)
         print(name, len(data["cases"][name]["digests"]) - 1, "steps,", len(data["cases"][name]["obs_nonzero"]), "observations")
+    data["squad_agents"] = run_squad_agents()
+    print("squad_agents", len(data["squad_agents"]["digests"]) - 1, "steps")
     with open(os.path.join(HERE, "ref_traj.json"), "w") as f:
         json.dump(data, f, separators=(",", ":"), sort_keys=True)
         f.write("\n")

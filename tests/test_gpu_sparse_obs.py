@@ -125,3 +125,43 @@ def test_crowded_windows_are_marked_not_truncated():
             assert np.array_equal(k[a, :m], (ch * 9) | (y << 9) | (x << 14))
             assert np.array_equal(v[a, :m].view(np.uint32), obs[a][nz[:m]].view(np.uint32))
     print("agents marked as crowded:", marked)
+
+
+@pytest.mark.parametrize("which,cap,arenas", [("C2", 16, 8), ("C3", 200, 24), ("MAXCAP", 2048, 4)])
+def test_agents_whose_list_does_not_fit_are_evaluated_from_the_dense_fallback(which, cap, arenas):
+    """No agent is ever evaluated on a blank window: with sf_observe_overflow_device + sf_policy_forward_sparse_or_dense
+    the agents whose list did not fit — a cap far too small (16: every agent), a cap that cuts some lists (200), the
+    crowded-window marker (MAXCAP) — are redone from their dense observation on the device, no host round trip.  The
+    outputs equal the dense pair of calls bit for bit over recurrent steps, for every agent; nothing is counted."""
+    w = config.baseline_workload(which, arenas=arenas)
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    B = w.cfg.arenas * w.cfg.n_agents
+    params = policy.init_parameters(seed=4)
+    dense, sparse = policy.PolicyBatch(params, B), policy.PolicyBatch(params, B)
+    d_obs = torch.zeros((B, 32, 31, 31), dtype=torch.float32, device="cuda")
+    d_fb = torch.full((B, 32, 31, 31), float("nan"), dtype=torch.float32, device="cuda")  # rows nobody writes must not be read
+    keys = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    vals = torch.zeros((B, cap), dtype=torch.float32, device="cuda")
+    counts, pov = torch.zeros(B, dtype=torch.int32, device="cuda"), torch.zeros((B, 160), device="cuda")
+    out = [(torch.zeros((B, 9), device="cuda"), torch.zeros(B, device="cuda")) for _ in range(2)]
+    flagged = 0
+    for _ in range(4):
+        _advance(w, g, 40)
+        g.observe_device(d_obs.data_ptr())
+        dense.forward(d_obs.data_ptr(), B, out[0][0].data_ptr(), out[0][1].data_ptr())
+        g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), cap)
+        g.observe_overflow_device(counts.data_ptr(), cap, d_fb.data_ptr(), pov.data_ptr())
+        sparse.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), cap, B,
+                              out[1][0].data_ptr(), out[1][1].data_ptr(), d_dense_ptr=d_fb.data_ptr())
+        g.synchronize(), dense.synchronize(), sparse.synchronize()
+        n = counts.cpu().numpy().view(np.uint32)
+        flagged += int(((n > cap) | (n == 0xFFFFFFFF)).sum())
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        for b in range(B):
+            hd, ad = dense.get_memory(b)
+            hs, as_ = sparse.get_memory(b)
+            assert np.array_equal(hd, hs)
+    assert sparse.sparse_overflows() == 0
+    if which != "MAXCAP":
+        assert flagged > 0

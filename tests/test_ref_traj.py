@@ -54,3 +54,42 @@ def test_reproduces_the_references_trajectory(name, impl, ulp_tol):
             assert ulp <= ulp_tol, "%s: observation after %d steps differs from the reference's by %d ulp" % (name, s, ulp)
         if s < steps:
             sim.step(cmds[s])
+
+
+@pytest.mark.parametrize("impl,ulp_tol", IMPLS)
+def test_reproduces_the_references_squad_agents_game(impl, ulp_tol):
+    """The reference built with USE_AGENT_IN_SQUAD_NPCS (ten Agents in one Squad game): digests of every step; the
+    observation the reference gave agent 0 at the loop top = sf_observe before the step, the ones it gave the other
+    agents inside human_action (gameplay.hpp:988-999) = sf_observe between sf_step_begin and sf_step_end; which humans
+    still have an Agent = sf_agent_alive."""
+    import test_squad_agents_example as X
+    from strikeforce_amd import abi
+    gold = GOLD["squad_agents"]
+    w = ref_cases.native(abi.MODE_SQUAD, 2, ref_cases.RICH, maps="shipped")
+    w.cfg.n_agents = 10
+    sim = impl(w)
+    sim.reset((C.c_uint64 * 1)(gold["tb"]), (C.c_uint64 * 1)(gold["serial"]))
+    steps = len(gold["digests"]) - 1
+
+    def dense(text):
+        v = np.zeros(32 * 31 * 31, dtype=np.uint32)
+        for t in text.split():
+            i, x = t.split(":")
+            v[int(i, 16)] = int(x, 16)
+        return v.view(np.int32).astype(np.int64)
+
+    for s in range(steps):
+        assert "%016x" % int(sim.digest()[0]) == gold["digests"][s], "state after %d steps" % s
+        want = gold["agent_obs_nonzero"].get(str(s))
+        top = sim.observe()[0] if want else None
+        sim.step_begin()
+        if want:
+            mid = sim.observe()[0]
+            assert len(want) >= 5
+            for g, text in want.items():
+                got = np.ascontiguousarray((top if g == "0" else mid)[int(g)]).reshape(-1).view(np.int32).astype(np.int64)
+                assert int(np.abs(got - dense(text)).max()) <= ulp_tol, "step %d agent %s" % (s, g)
+        chars = "".join(X.ACTS[X.policy(g, s)] for g in range(10))
+        sim.step_end(np.frombuffer(chars.encode(), dtype=np.uint8))
+        assert "".join(str(int(x)) for x in sim.agent_alive()[0]) == gold["agent_alive_after_step"][s], "step %d" % s
+    assert "%016x" % int(sim.digest()[0]) == gold["digests"][steps]
