@@ -14,7 +14,7 @@
 //   init <profile file> <Solo|Timer|Squad> <level> <agents 0|1>
 //   reset <tb> <serial>             setup(); _srand(tb, serial); ++frame; loop-top spawns
 //   step <chars>                    one iteration of play()'s loop + the next loop top; chars[0] = the player's command,
-//                                   chars[k] = the scripted action of agent k (agents mode)
+//                                   chars[k] = the scripted action of human k's agent (where it has one)
 //   dump <H> <Z> <B> <P>            state of the first H/Z/B/P slots and of every cell, in sf_*_rec word order
 //   calls                           predict/update calls since the last `calls`
 //   obs <agent id>                  the observation that agent's last predict() received (30752 hex words)
@@ -113,7 +113,10 @@ void half_tick(int k) {  // gameplay.hpp:1457-1463 == 1465-1471 (view / find_rec
 }
 
 void one_step(const std::string &cmds) {
-    for (size_t k = 0; k < cmds.size(); ++k) script[(int)k] = cmds[k];
+    // chars[k] is the command of human slot k.  Agents are numbered in the order prepare() made them: the player's first
+    // when the player has one; with a keyboard player (agents 0) and USE_AGENT_IN_SQUAD_NPCS, human k's agent is k - 1
+    const size_t off = using_an_agent ? 0 : 1;
+    for (size_t k = off; k < cmds.size(); ++k) script[(int)(k - off)] = cmds[k];
     // get_my_action, gameplay.hpp:955-958 (my_command = the keyboard: the scripted char is what was "typed")
     command[ind] = cmds.empty() ? '+' : cmds[0];
     if (using_an_agent) {
