@@ -149,6 +149,12 @@ struct Core {
     return (uint32_t)(o + ((o >> 31) & 65537)) & 1023u;
   }
   static SF_DEV uint32_t draw(Arena &S, const uint8_t *, const Params &p) {  // RN:54-62
+#ifdef SF_EXP_FAKE_DRAWS
+    // timing build only (tools/experiments/r03_rows): what a draw would cost if it came out of a ring filled by producer
+    // waves — one v_readlane and a few scalar instructions.  Wrong results by construction; never the product library.
+    S.jomle = S.jomle * 1664525u + 1013904223u;
+    return (W::readlane(S.rl, (S.jomle >> 26) & 31u) ^ (S.jomle >> 16)) & 1023u;
+#endif
     SF_PROF(PH_RNG);
     S.jomle += 1u;
     // rotate left, new value last (+ copy on 18).  Neither jomle nor the product is reduced mod 2^16: every consumer of
@@ -185,6 +191,10 @@ struct Core {
     S.la2_ok = 1u;
   }
   static SF_DEV void prewarm_one(Arena &S, const Params &p) {
+#ifdef SF_EXP_FAKE_DRAWS
+    S.warm = 1024u;
+    return;
+#endif
     SF_PROF(PH_WARM);
     if (S.warm >= 1024u) return;
     uint32_t j2 = 18u + S.warm;

@@ -35,6 +35,14 @@ for wl in sys.argv[1:] or ["C2", "C3"]:
     per = out.astype(np.float64).mean(axis=0) / K
     tot = per[:14].sum()
     print("%s: %.0f wave cycles per arena-step" % (wl, tot))
+    life = out[:, :14].astype(np.float64).sum(axis=1) / K  # per arena: stamped cycles per step over this launch
+    order = np.argsort(life)
+    print("   per arena: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f (max / mean %.2f)"
+          % (life.mean(), life[order[A // 2]], life[order[int(A * 0.9)]], life[order[int(A * 0.99)]], life.max(), life.max() / life.mean()))
+    top = order[-41:]  # the busiest 1 %: where do THEIR cycles go?
+    pt = out[top].astype(np.float64).mean(axis=0) / K
+    print("   busiest 1 %% of the arenas: %.0f cycles per step: " % pt[:14].sum() +
+          ", ".join("%s %.0f" % (NAMES[i], pt[i]) for i in np.argsort(-pt[:14])[:6]))
     for i, n in enumerate(NAMES):
         print("   %-14s %8.0f  %5.1f %%" % (n, per[i], 100 * per[i] / tot))
     g.close()

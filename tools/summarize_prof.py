@@ -31,6 +31,21 @@ os.makedirs(dst, exist_ok=True)
 
 for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, tag + "_kernel_stats.csv"))
+# round 3: the driver's own command (--steps 20 --warmup 5: 21 repeats of one 20-step launch, side measurements off, so
+# the LAST 21 k_step dispatches are the timed region's) traced in its own run
+for f in glob.glob(os.path.join(src, "stats20", "*", "*_kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, tag + "_driver_form_kernel_stats.csv"))
+for f in glob.glob(os.path.join(src, "stats20", "*", "*_kernel_trace.csv")):
+    rows = [r for r in csv.DictReader(open(f)) if "k_step" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    last = d[-21:]
+    json.dump({"command": "python bench.py --steps 20 --warmup 5 (side measurements off)", "k_step_dispatches": len(d),
+               "timed_region_dispatches": len(last), "k_step_K20_timed_avg_ms": sum(last) / len(last) / 1e6,
+               "k_step_K20_timed_min_ms": min(last) / 1e6, "k_step_K20_timed_max_ms": max(last) / 1e6,
+               "all_dispatch_ms": [x / 1e6 for x in d]},
+              open(os.path.join(dst, tag + "_driver_form_kernel_summary.json"), "w"), indent=1)
+    print("driver form: last 21 k_step dispatches avg %.4f ms" % (sum(last) / len(last) / 1e6))
 for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
     rows = list(csv.DictReader(open(f)))
     keep = [r for r in rows if "sf::" in r["Kernel_Name"] or "sfp::" in r["Kernel_Name"]]
