@@ -19,6 +19,12 @@
 //   calls                           predict/update calls since the last `calls`
 //   obs <agent id>                  the observation that agent's last predict() received (30752 hex words)
 //   observe <slot>                  Custom.hpp's window encoding for hum[slot] now (through a probe agent)
+//   logging <0|1>                   enable_logging (gameplay.hpp:438): the reference's own .sf_sample writer
+//   replay <0|1>                    replay_mode: the next reset_native reads the sample's path from the NEXT stdin line
+//                                   (load_data's own prompt, gameplay.hpp:1750-1763) and takes seeds, record and commands from it
+//   reset_native                    setup() with the seeds it makes itself (time(), libc rand: gameplay.hpp:1233,1745-1747)
+//                                   or, in replay mode, reads from the sample; answers "ok <tb> <serial>"
+//   logclose                        closes the log; answers its path (relative to the working directory)
 //   bench <steps> <seed>            timing (bench.py's cpu_baseline): `steps` iterations under the 28-command random agent
 //                                   of SURVEY §8d (LCG x <- 1664525 x + 1013904223, command (x >> 16) % 28); when the
 //                                   player is dead the game is set up again with tb + 1 (check_end is not in the build)
@@ -252,6 +258,23 @@ int main() {
             ++g.frame;   // gameplay.hpp:1441
             loop_top();
             printf("ok\n");
+        } else if (s.rfind("logging ", 0) == 0) {
+            g.enable_logging = atoi(s.c_str() + 8) != 0;
+            g.log_filename.clear();
+            printf("ok\n");
+        } else if (s.rfind("replay ", 0) == 0) {
+            g.replay_mode = atoi(s.c_str() + 7) != 0;
+            printf("ok\n");
+        } else if (s == "reset_native") {
+            g.chest = 0;
+            g.setup();  // load_data(): srand(tb) ... _srand(tb, serial_number), or the sample's header in replay mode
+            steps = 0;
+            ++g.frame;
+            loop_top();
+            printf("ok %lld %lld\n", (long long)g.tb, g.serial_number);
+        } else if (s == "logclose") {
+            g.log_file.close();
+            printf("ok %s\n", g.log_filename.c_str());
         } else if (s.rfind("step", 0) == 0) {
             one_step(s.size() > 5 ? s.substr(5) : std::string());
             printf("ok %lld %lld %lld %lld %lld %lld\n", phase_draws[0], phase_draws[1], phase_draws[2], phase_draws[3],

@@ -101,6 +101,36 @@ class RefTick:
     def reset(self, tb, serial):
         assert self._cmd("reset %d %d" % (tb, serial)) == ["ok"]
 
+    def logging(self, on):
+        assert self._cmd("logging %d" % int(on)) == ["ok"]
+
+    def reset_native(self, replay_path=None):
+        """setup() with its own seeds (time(), libc rand) — or, with replay_path, in replay mode from that .sf_sample:
+        load_data asks for the path on stdin (gameplay.hpp:1750-1763).  Returns (tb, serial_number) as the game has them."""
+        if replay_path is not None:
+            assert self._cmd("replay 1") == ["ok"]
+            self.p.stdin.write("reset_native\n%s\n" % replay_path)
+            self.p.stdin.flush()
+            out = []
+            while True:
+                ln = self.p.stdout.readline()
+                if not ln:
+                    raise RuntimeError("sf_ref_tick died in replay setup")
+                if ln.rstrip("\n") == "end":
+                    break
+                out.append(ln.rstrip("\n"))
+            r = [x for x in out if x.startswith("ok ") or x.endswith(" ok")] or out[-1:]
+            # load_data's prompt ("Enter the file's address: ") shares the line with the answer
+            t = out[-1].split("ok ")[-1].split()
+        else:
+            r = self._cmd("reset_native")
+            t = r[-1].split()[1:]
+        return int(t[0]), int(t[1])
+
+    def logclose(self):
+        r = self._cmd("logclose")
+        return os.path.join(self.dir, r[0].split(" ", 1)[1])
+
     def step(self, chars):
         """chars: bytes/str, chars[0] the player's command, chars[k] agent k's scripted action."""
         if isinstance(chars, (bytes, bytearray, np.ndarray)):
