@@ -18,13 +18,15 @@ The one class the reference leaves to the user is `Agent` (random.hpp:25 -> sele
 Agent.hpp; bots/bot-0/Agent.hpp:27-37 is the minimal form): ref_tick_main.cpp supplies a scripted one, which is the
 plug-in contract, not a stand-in.  What ref_tick_main.cpp restates from the omitted play() is the ORDER of its calls
 (gameplay.hpp:1441-1471, fifteen lines) and get_my_action's two lines that fetch the player's command
-(gameplay.hpp:955-958); check_end (gameplay.hpp:1102-1229: screens and key waits around four comparisons) stays out,
-so SURVEY §8 row a19 remains pinned by hand-derived scenarios only.
+(gameplay.hpp:955-960, incl. client.send_it() in an online match); check_end (gameplay.hpp:1102-1229: screens and key
+waits around five comparisons) stays out, so SURVEY §8 row a19 remains pinned by hand-derived scenarios only.
 
 Pins (tests/test_ref_tick.py): rows a4-a18 and a20 — Backpack/Human, gen_human, node/showit, the slot allocators, the
 three spawns, zombie_action, portal_damage, update_tmp, hit_human/hit_zombie, update_bull, human_action / get_command /
 human_rnpc_bot, obey, teleport, claim_chest, setup/load_data (Solo, Timer, Squad), describe + gameplay::bot — on the
-reference's native world (gameplay.hpp:37: 3 floors x 30 x 100, its caps of 9000 never reached).
+reference's native world (gameplay.hpp:37: 3 floors x 30 x 100, its caps of 9000 never reached).  Also: load_data's
+logging / replay branches (.sf_sample, tests/test_ref_replay.py) and its online branch + class Client, in a real match
+through the reference's own server (tests/test_lockstep_server.py).
 
 Patched dimensions (second flavour, `build(dims=(F, N, M, H, Z, B, C))` -> oracle/_ref/sf_ref_tick_<dims>): the
 reference's world size and slot-pool caps are compile-time constants on ONE line, gameplay.hpp:37.  For BASELINE.json's

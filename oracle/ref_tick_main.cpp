@@ -11,7 +11,11 @@
 // actions and records what it was called with.
 //
 // Protocol: one command per line on stdin, one answer block per command on stdout, each block ended by a line "end".
-//   init <profile file> <Solo|Timer|Squad> <level> <agents 0|1>
+//   init <profile file> <Solo|Timer|Squad|Battle_Royal> <level> <agents 0|1>
+//                                   Battle_Royal = the online mode "Battle Royal" (gameplay.hpp:1235): reset_native then joins a
+//                                   match server — load_data asks for IP, port and password on the next three stdin lines
+//                                   (gameplay.hpp:1806-1817) — as the reference client does; `step` sends the player's command
+//                                   (client.send_it, gameplay.hpp:959-960) and human_action receives the others' (:977-978)
 //   reset <tb> <serial>             setup(); _srand(tb, serial); ++frame; loop-top spawns
 //   step <chars>                    one iteration of play()'s loop + the next loop top; chars[0] = the player's command,
 //                                   chars[k] = the scripted action of human k's agent (where it has one)
@@ -129,6 +133,7 @@ void one_step(const std::string &cmds) {
         char c = g.bot(hum[ind]);
         if (!g.manual && command[ind] != '3') command[ind] = c;
     }
+    if (g.online && !g.replay_mode) client.send_it();  // gameplay.hpp:959-960
     // draws per phase (the generator's own counter, random.hpp:29): zombie_action, update_bull (1st), human_action,
     // update_bull (2nd), the next loop top, everything else
     long long &j = Environment::Random::jomle, j0 = j;
@@ -242,6 +247,8 @@ int main() {
             if (sscanf(s.c_str() + 5, "%2047s %63s %d %d", path, mode, &level, &agents) != 4) { printf("error init\nend\n"); fflush(stdout); continue; }
             user = "ref_tick";
             CH::me.build(false, "", path);  // Character.hpp:650 with an explicit file (enter.hpp:43 reads the account's)
+            for (char *q = mode; *q; ++q)
+                if (*q == '_') *q = ' ';
             g.mode = mode, g.level = level, g.manual = !agents;
             printf("ok dims %d %d %d %d %d %d %d\n", F, N, M, H, Z, B, C);
         } else if (s.rfind("reset ", 0) == 0) {
@@ -267,11 +274,16 @@ int main() {
             printf("ok\n");
         } else if (s == "reset_native") {
             g.chest = 0;
-            g.setup();  // load_data(): srand(tb) ... _srand(tb, serial_number), or the sample's header in replay mode
+            g.setup();  // load_data(): srand(tb) ... _srand(tb, serial_number), or the sample's header in replay mode,
+                        // or (online) the match server's seed, indices, teams and the other players' records
+            if (g.online && !g.replay_mode && !disconnect) client.prepare();  // gameplay.hpp:1432-1433
             steps = 0;
             ++g.frame;
             loop_top();
-            printf("ok %lld %lld\n", (long long)g.tb, g.serial_number);
+            if (g.online)
+                printf("ok %lld %lld %d %d %d %d\n", client.tb, g.serial_number, ind, client.n, client.team, (int)disconnect);
+            else
+                printf("ok %lld %lld\n", (long long)g.tb, g.serial_number);
         } else if (s == "logclose") {
             g.log_file.close();
             printf("ok %s\n", g.log_filename.c_str());

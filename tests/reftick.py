@@ -14,7 +14,7 @@ from strikeforce_amd import abi, config
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "sf_ref_tick")
 REF_CLIENT = "/root/reference/StrikeForce-client"
-MODES = {abi.MODE_SOLO: "Solo", abi.MODE_TIMER: "Timer", abi.MODE_SQUAD: "Squad"}
+MODES = {abi.MODE_SOLO: "Solo", abi.MODE_TIMER: "Timer", abi.MODE_SQUAD: "Squad", abi.MODE_BATTLE: "Battle_Royal"}
 
 
 NATIVE = (3, 30, 100, 9000, 9000, 9000, 9000)  # gameplay.hpp:37
@@ -65,8 +65,13 @@ class RefTick:
             with open(os.path.join(self.dir, "map", "floor%d.txt" % (f + 1)), "w") as fh:
                 fh.write(config.format_floor_text(chars[f * cells:(f + 1) * cells], portal[f * cells:(f + 1) * cells],
                                                   cfg.rows, cfg.cols))
+        blob = "player\n" + "\n".join(str(int(t)) for t in player_tokens) + "\n"
         with open(os.path.join(self.dir, "profile.txt"), "w") as fh:
-            fh.write("player\n" + "\n".join(str(int(t)) for t in player_tokens) + "\n")
+            fh.write(blob)
+        # the account file Client::give_info sends to the match server (gameplay.hpp:120-131); user = "ref_tick"
+        os.makedirs(os.path.join(self.dir, "accounts", "game", "ref_tick"))
+        with open(os.path.join(self.dir, "accounts", "game", "ref_tick", "info, ref_tick.txt"), "w") as fh:
+            fh.write(blob)
         self.p = subprocess.Popen([exe], cwd=self.dir, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
         r = self._cmd("init profile.txt %s %d %d" % (MODES[cfg.mode], cfg.level, int(agents)))
         assert r and r[0] == "ok dims " + " ".join(str(d) for d in dims), r
@@ -103,6 +108,23 @@ class RefTick:
 
     def logging(self, on):
         assert self._cmd("logging %d" % int(on)) == ["ok"]
+
+    def join_match(self, host, port, password):
+        """Battle_Royal: setup() -> load_data() asks for the server's IP, port and password on stdin and joins the match
+        (gameplay.hpp:1806-1830).  Blocks until the server has all players.  Returns (tb, serial, ind, n, team)."""
+        self.p.stdin.write("reset_native\n%s\n%d\n%s\n" % (host, port, password))
+        self.p.stdin.flush()
+        out = []
+        while True:
+            ln = self.p.stdout.readline()
+            if not ln:
+                raise RuntimeError("sf_ref_tick died while joining the match")
+            if ln.rstrip("\n") == "end":
+                break
+            out.append(ln.rstrip("\n"))
+        t = [int(x) for x in out[-1].split("ok ")[-1].split()]
+        assert t[5] == 0, "the reference client could not connect: %r" % out
+        return tuple(t[:5])
 
     def reset_native(self, replay_path=None):
         """setup() with its own seeds (time(), libc rand) — or, with replay_path, in replay mode from that .sf_sample:

@@ -163,3 +163,87 @@ def test_three_gpu_clients_through_the_reference_server():
     teams = [1, 2, 3]
     results, worlds, out = run_match(env.ArenaBatch, teams, ticks=200)
     _check(results, worlds, out, teams)
+
+
+# ---- the REFERENCE CLIENT in the match ---------------------------------------------------------------------------------
+def test_the_reference_client_and_two_of_ours_play_one_match():
+    """The online branch of load_data (gameplay.hpp:1795-1859: join, exchange records, the shared seed, random start
+    cells and facings), Client::send_it / recieve (:113-118,170-193) and human_action's handling of remote players
+    (:977-993), on the reference's own client: oracle/_ref/sf_ref_tick (oracle/ref_tick.py, mode "Battle Royal") joins the
+    reference's own server as one of three players; the other two are strikeforce_amd.lockstep clients.  Afterwards a
+    shadow oracle with the reference client's `ind`, fed with the commands the match relayed, must equal the reference
+    client's whole world after every iteration — including the kill / loot counters, which are kept relative to `ind`."""
+    import reftick
+    if not reftick.available():
+        pytest.skip("oracle/_ref/sf_ref_tick not built")
+    from oracle_lib import Oracle
+    rich = [15000, 1000, 15000, 10, 10, 10, 300000, 60, 0, 0, 0, 1, 1, 1, 34] + [1] * 16 + [56]  # nobody dies in 120 iterations
+    teams, ticks = [1, 2, 3], 120
+    port, password = _free_port(), "sesame"
+    proc = _start_server(port, password, teams)
+    m, portal = config.synthetic_map(28, 36, wall_p=0.04, portal_pairs=1)
+    cfg0 = config.make_config(1, 28, 36, H=12, Z=10, B=48, P=8, mode=abi.MODE_BATTLE, n_agents=3, teams=teams, auto_reset=0,
+                              player_tokens=rich)
+    ref = reftick.RefTick(config.Workload("match", cfg0, m, portal), rich, native_caps=False)
+    errors, ours, relayed, ref_dumps, ref_info = [], {}, {}, {}, {}
+
+    def ref_thread():
+        try:
+            tb, serial, ind, n, team = ref.join_match("127.0.0.1", port, password)
+            ref_info.update(tb=tb, serial=serial, ind=ind, n=n, team=team)
+            rng = np.random.RandomState(77)
+            ref_dumps[-1] = ref.dump()
+            for it in range(ticks):
+                ref.step(abi.BENCH_COMMANDS[rng.randint(0, 28)])
+                ref_dumps[it] = ref.dump()
+        except Exception as e:  # noqa: BLE001
+            errors.append(("reference client", repr(e)))
+
+    def our_thread(k):
+        try:
+            c = lockstep.MatchClient("127.0.0.1", port, password, rich, name="p%d" % k).connect()
+            sim = Oracle(c.workload(28, 36, m, portal, H=12, Z=10, B=48, P=8))
+            ours[c.ind] = c
+            rng = np.random.RandomState(1000 + c.ind)
+            policy = lambda _s, it: abi.BENCH_COMMANDS[rng.randint(0, 28)]
+            # the commands of every iteration, as this client stepped them
+            orig_step = sim.step
+
+            def step(cmd):
+                relayed.setdefault(c.ind, []).append(bytes(cmd))
+                orig_step(cmd)
+            sim.step = step
+            lockstep.play(c, sim, policy, max_iterations=ticks)
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=our_thread, args=(0,)), threading.Thread(target=ref_thread), threading.Thread(target=our_thread, args=(2,))]
+    for t in threads:
+        t.start()
+        time.sleep(0.4)  # connection order = player index
+    for t in threads:
+        t.join(timeout=120)
+    ref.close()
+    try:
+        proc.stdin.write("done!\\n")
+        proc.stdin.flush()
+        proc.wait(timeout=20)
+    except Exception:  # noqa: BLE001
+        proc.kill()
+    assert not errors, errors
+    assert ref_info["ind"] == 1 and ref_info["n"] == 3 and ref_info["team"] == 2
+    c0 = ours[0]
+    assert (c0.tb, c0.serial) == (ref_info["tb"], ref_info["serial"])
+    assert relayed[0] == relayed[2] and len(relayed[0]) == ticks
+    # the shadow: this repo's simulation as the reference client's process sees the match (ind = 1)
+    cfg = config.make_config(1, 28, 36, H=12, Z=10, B=48, P=8, mode=abi.MODE_BATTLE, level=1, n_agents=3, teams=c0.teams,
+                             auto_reset=0, player_tokens=rich, ind=1, agent_tokens=c0.records)
+    shadow = Oracle(config.Workload("shadow", cfg, m, portal))
+    import ctypes as C
+    shadow.reset((C.c_uint64 * 1)(c0.tb), (C.c_uint64 * 1)(c0.serial))
+    d = reftick.first_difference(ref_dumps[-1], reftick.arrays_of(shadow.dump(0)))
+    assert d is None, "after the placement: " + d
+    for it in range(ticks):
+        shadow.step(np.frombuffer(relayed[0][it], dtype=np.uint8))
+        d = reftick.first_difference(ref_dumps[it], reftick.arrays_of(shadow.dump(0)))
+        assert d is None, "iteration %d: %s" % (it, d)
