@@ -41,7 +41,48 @@ __global__ __launch_bounds__(64) void k_reset(Params p, const uint64_t *tb, cons
 template <int NB, bool HP, bool BM>
 __global__ __launch_bounds__(64) void k_step(Params p, const uint8_t *cmds, int k) {
   extern __shared__ __attribute__((aligned(2048))) uint8_t lds[];  // the RNG power table comes first (W::pow_pair)
-  Core<WaveGfx950, NB, HP, BM>::step_body(lds, p, (int)blockIdx.x, cmds, k);
+  const int a = p.perm ? (int)gptr(p.perm)[blockIdx.x] : (int)blockIdx.x;
+  Core<WaveGfx950, NB, HP, BM>::step_body(lds, p, a, cmds, k);
+}
+
+// Launch order for k_step: arenas by population (live zombies + live humans as the last store() recorded them, SC_LOAD),
+// in SNAKE order — blocks of 1024 alternately descending and ascending.  A step's cost grows with the arena's population
+// and a launch ends with its slowest wavefront; the dispatcher hands consecutive workgroups to different SIMDs, so with
+// this order the four arenas that share a SIMD are one of each load quartile with about equal sums per SIMD, the busiest
+// arenas start first, and a busy arena's neighbours finish early and leave it the SIMD.  Measured on configs[2] (same-call
+// A/B, tools/r03_balance_ab.sh): 186.7 -> 204.8 M env-steps/s, 20-step launches 172 -> 189 M; configs[1] (all arenas at
+// the zombie cap: nothing to order) unchanged; keyed by the arena's measured cycles per step instead: +1.6 % only (an
+// arena's time depends on its neighbours, so that key chases itself).  One workgroup; a counting sort over 65 classes,
+// ties in any order: arenas are independent, the order never shows in any result.
+__global__ __launch_bounds__(1024) void k_rank(Params p, uint16_t *perm) {
+  __shared__ uint32_t hist[72];
+  const int t = (int)threadIdx.x;
+  if (t < 72) hist[t] = 0u;
+  __syncthreads();
+  uint32_t cls[4];  // A <= 4096: at most four arenas per thread
+  int cnt = 0;
+  for (int a = t; a < p.A && cnt < 4; a += 1024) {
+    uint32_t n = (uint32_t)gptr(p.scal)[(size_t)a * SC_WORDS + SC_LOAD];
+    n = n > 64u ? 64u : n;
+    cls[cnt++] = 64u - n;  // class 0 = the busiest
+    atomicAdd(&hist[64u - n], 1u);
+  }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (int c = 0; c < 65; ++c) {
+      const uint32_t n = hist[c];
+      hist[c] = run;
+      run += n;
+    }
+  }
+  __syncthreads();
+  cnt = 0;
+  for (int a = t; a < p.A && cnt < 4; a += 1024) {
+    uint32_t pos = atomicAdd(&hist[cls[cnt++]], 1u);  // rank, busiest first
+    if (p.A == 4096 && ((pos >> 10) & 1u)) pos = (pos & ~1023u) | (1023u - (pos & 1023u));  // every second block backwards
+    gptr(perm)[pos] = (uint16_t)a;
+  }
 }
 
 // sf_step_begin / sf_step_end: one half of one iteration (sf_core.hpp step<1> / step<2>)
@@ -536,6 +577,13 @@ struct HipRT {
       hipLaunchKernelGGL((k_step<NB, true, false>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, k);
     SF_HIP(hipGetLastError());
     if (ev) SF_HIP(hipEventRecord(ev->second, stream));
+    return SF_OK;
+  }
+  bool can_rank() const { return true; }
+  int launch_rank(const Params &p, uint16_t *perm) {
+    SF_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_rank, dim3(1), dim3(1024), 0, stream, p, perm);
+    SF_HIP(hipGetLastError());
     return SF_OK;
   }
   int launch_step(const Params &p, int NB, const uint8_t *cmds, int k) {

@@ -1608,6 +1608,8 @@ struct Core {
     W::setlane(sc, SC_SR_LO, S.sr_lo), W::setlane(sc, SC_SR_HI, S.sr_hi);
     W::setlane(sc, SC_DRAWS, S.jomle - (18u + 1024u));  // _rand() calls since the episode's _srand: jomle counts them
     W::setlane(sc, SC_WARM, S.warm);
+    W::setlane(sc, SC_LOAD, (uint32_t)(W::popc64(W::ballot(((S.zpos & ZF_ALIVE) != 0u) & W::ltu(ln, (uint32_t)p.Z))) +
+                                       W::popc64(W::ballot(((S.hfl & HF_ALIVE) != 0u) & W::ltu(ln, (uint32_t)p.H)))));
     W::gstore((uint32_t *)p.scal + (size_t)a * SC_WORDS, ln, sc, W::ltu(ln, (uint32_t)SC_WORDS));
     if (!HBM_PLANE && S.dirty) W::copy_l2g(p.flags + (size_t)a * (size_t)p.cells_pad, lds, (uint32_t)p.cells_pad);
   }

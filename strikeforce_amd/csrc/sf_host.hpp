@@ -190,6 +190,9 @@ struct Env {
   uint32_t *d_exptab = nullptr;
   uint64_t *d_tb = nullptr, *d_serial = nullptr;
   uint8_t *d_cmd = nullptr;
+  uint16_t *d_perm = nullptr;  // k_step's launch order (k_rank): arenas by population; long launches of <= 4096 arenas
+  int balance = -1;            // SF_BALANCE=0 switches the ordering off (A/B measurements)
+  int steps_since_rank = 1 << 30;  // the order is renewed every >= 100 steps (populations change by one every 20-25 steps)
   float *d_obs = nullptr;
   uint32_t *d_nzprev = nullptr;      // [A * n_agents][961] which floats of the delta-tracked buffer are non-zero
   const float *delta_ptr = nullptr;  // the buffer d_nzprev describes
@@ -339,7 +342,7 @@ struct Env {
 
   void destroy() {
     void *ptrs[] = {d_logt, d_exptab, d_tab, d_map_flags, d_map_pidx, d_map_exits, p.hum, p.zom, p.bul, p.por, p.rng, p.rng2, p.scal, p.results,
-                    p.flags, p.aux_dmg, p.aux_pidx, d_tb, d_serial, d_cmd, d_obs, d_nzprev};
+                    p.flags, p.aux_dmg, p.aux_pidx, d_tb, d_serial, d_cmd, d_obs, d_nzprev, d_perm};
     for (void *q : ptrs)
       if (q) rt.free(q);
     rt.shutdown();
@@ -354,6 +357,7 @@ struct Env {
     if (rc) return rc;
     was_reset = true;
     mid_step = false;
+    steps_since_rank = 1 << 30;
     return rt.sync();
   }
 
@@ -368,7 +372,24 @@ struct Env {
     if (!d_cmds || k < 1) return fail(SF_ERR_ARG, "bad command buffer / step count");
     if (!was_reset) return fail(SF_ERR_STATE, "sf_step_device before sf_reset");
     if (mid_step) return fail(SF_ERR_STATE, "sf_step_device between sf_step_begin and sf_step_end");
-    return rt.launch_step(p, NB, d_cmds, k);
+    // long launches: order the arenas by population first, so that the ones sharing a SIMD are of different loads (k_rank)
+    if (balance < 0) {
+      const char *e = getenv("SF_BALANCE");
+      balance = (e && e[0] == '0') ? 0 : 1;
+    }
+    Params q = p;
+    // (maps whose flag plane stays in HBM gained nothing from the order in measurements: left alone)
+    if (balance && k >= 8 && p.A <= 4096 && p.A >= 1024 && rt.can_rank() && !hbm_plane(p.cells_pad)) {
+      int rc;
+      if (!d_perm && (rc = alloc(d_perm, (size_t)p.A))) return rc;
+      if (steps_since_rank >= 100) {
+        if ((rc = rt.launch_rank(p, d_perm))) return rc;
+        steps_since_rank = 0;
+      }
+      steps_since_rank += k;
+      q.perm = d_perm;
+    }
+    return rt.launch_step(q, NB, d_cmds, k);
   }
   // the iteration in two halves (the reference queries the agents of humans other than `ind` between them, G:988-999)
   int step_begin() {

@@ -59,7 +59,9 @@ constexpr uint32_t PF_ACTIVE = 1u << 31;
 
 // ---- per-arena scalar block: 24 dwords ----------------------------------------------------------------
 enum { SC_FRAME = 0, SC_KILLS, SC_TKILLS, SC_LOOT, SC_CHESTS, SC_JOMLE, SC_STEPS, SC_EPISODES, SC_DONE, SC_OUTCOME,
-       SC_ENDED, SC_TB_LO, SC_TB_HI, SC_SR_LO, SC_SR_HI, SC_DRAWS, SC_WARM, SC_WORDS = 24 };
+       SC_ENDED, SC_TB_LO, SC_TB_HI, SC_SR_LO, SC_SR_HI, SC_DRAWS, SC_WARM,
+       SC_LOAD /* live zombies + live humans when the state was stored: k_rank's key, not part of the game state */,
+       SC_WORDS = 24 };
 constexpr int RNG_WORDS = 18;
 
 // ---- derived per-profile tables (Human::build, Character.hpp:650-709) ---------------------------------
@@ -126,6 +128,10 @@ struct Params {
   const uint16_t *logt;      // [LOGT_OFF + 65537] log_3 of the residue (j - LOGT_OFF) mod 65537 at index j, 0 for residue 0
                              // (RNG, sf_core.hpp draw())
   const uint32_t *exptab;    // [512] 3^i (i < 256) then 3^(256 i): staged in LDS behind the flag plane
+  // k_step only: workgroup i steps arena perm[i] (null: arena i).  Arenas are independent, so the order changes nothing
+  // but which arenas share a SIMD: k_rank orders them by population, busiest first, so that every SIMD gets one arena
+  // of each load quartile instead of whatever the arena numbers bring together (sf_api.hip)
+  const uint16_t *perm;
 };
 
 // The log table is indexed by the half-reduced tap sum t = lo16(x) - hi16(x), x < 2^25, i.e. t in (-512, 65536):

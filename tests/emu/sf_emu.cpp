@@ -133,6 +133,8 @@ struct CpuRT {
     }
     return SF_OK;
   }
+  bool can_rank() const { return false; }  // (a launch order only matters where arenas run side by side)
+  int launch_rank(const Params &, uint16_t *) { return SF_OK; }
   int launch_step_half(const Params &p, int NB, const uint8_t *cmds, int phase) {
     switch (NB) {
       case 1: run_step_half<1>(p, cmds, phase); break;
