@@ -178,11 +178,12 @@ def test_the_reference_client_and_two_of_ours_play_one_match():
         pytest.skip("oracle/_ref/sf_ref_tick not built")
     from oracle_lib import Oracle
     rich = [15000, 1000, 15000, 10, 10, 10, 300000, 60, 0, 0, 0, 1, 1, 1, 34] + [1] * 16 + [56]  # nobody dies in 120 iterations
+    # (the reference pools exits by B, `portal[B]` gameplay.hpp:51-53, and a level-10 account carries ten portals: P = B here)
     teams, ticks = [1, 2, 3], 120
     port, password = _free_port(), "sesame"
     proc = _start_server(port, password, teams)
     m, portal = config.synthetic_map(28, 36, wall_p=0.04, portal_pairs=1)
-    cfg0 = config.make_config(1, 28, 36, H=12, Z=10, B=48, P=8, mode=abi.MODE_BATTLE, n_agents=3, teams=teams, auto_reset=0,
+    cfg0 = config.make_config(1, 28, 36, H=12, Z=10, B=48, P=48, mode=abi.MODE_BATTLE, n_agents=3, teams=teams, auto_reset=0,
                               player_tokens=rich)
     ref = reftick.RefTick(config.Workload("match", cfg0, m, portal), rich, native_caps=False)
     errors, ours, relayed, ref_dumps, ref_info = [], {}, {}, {}, {}
@@ -202,7 +203,7 @@ def test_the_reference_client_and_two_of_ours_play_one_match():
     def our_thread(k):
         try:
             c = lockstep.MatchClient("127.0.0.1", port, password, rich, name="p%d" % k).connect()
-            sim = Oracle(c.workload(28, 36, m, portal, H=12, Z=10, B=48, P=8))
+            sim = Oracle(c.workload(28, 36, m, portal, H=12, Z=10, B=48, P=48))
             ours[c.ind] = c
             rng = np.random.RandomState(1000 + c.ind)
             policy = lambda _s, it: abi.BENCH_COMMANDS[rng.randint(0, 28)]
@@ -236,7 +237,7 @@ def test_the_reference_client_and_two_of_ours_play_one_match():
     assert (c0.tb, c0.serial) == (ref_info["tb"], ref_info["serial"])
     assert relayed[0] == relayed[2] and len(relayed[0]) == ticks
     # the shadow: this repo's simulation as the reference client's process sees the match (ind = 1)
-    cfg = config.make_config(1, 28, 36, H=12, Z=10, B=48, P=8, mode=abi.MODE_BATTLE, level=1, n_agents=3, teams=c0.teams,
+    cfg = config.make_config(1, 28, 36, H=12, Z=10, B=48, P=48, mode=abi.MODE_BATTLE, level=1, n_agents=3, teams=c0.teams,
                              auto_reset=0, player_tokens=rich, ind=1, agent_tokens=c0.records)
     shadow = Oracle(config.Workload("shadow", cfg, m, portal))
     import ctypes as C
