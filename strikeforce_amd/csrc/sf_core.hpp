@@ -492,42 +492,53 @@ struct Core {
         hnear = hnear | W::select(zalive & ((qn0 == q) | (qn1 == q) | (qn2 == q) | (qn3 == q)), V(15u), V(0u));
       }
     }
-    const uint64_t near = W::ballot(hnear != 0u);
-    while (zm) {
-      const uint32_t z = (uint32_t)W::ctz64(zm);
-      const uint64_t bit = zm & (0ull - zm);
-      zm ^= bit;
-      if (skip & bit) continue;  // `if(themap[i][j][k].s[2]) continue;`
-      if (near & bit) {
-        // exact neighbour scan (the packed compare above can alias across a row end; this cannot)
-        const uint32_t q0 = W::readlane(zq, z);
-        const int f = pos_f(q0), r = pos_r(q0), c = pos_c(q0);
-        const int zmd = (int)W::readlane(S.zmd, z);
-        const uint32_t hn = W::readlane(hnear, z);
-        bool b = false;
-        for (int i1 = 0; i1 < 4; ++i1) {
-          if (!((hn >> i1) & 1u)) continue;
-          const int rr = r + DX(i1), cc = c + DY(i1);
-          if (!inmap(p, rr, cc)) continue;
-          const uint32_t q = pos_pack(f, rr, cc);
-          if (use_bm || human_at(S, q) >= 0) {
-            int index = b_ind(S, p);
-            if (refbullet_at(S, q) < 0 && index != -1)  // Zombie::punch CH:838-844
-              bullet_put(S, index, q, i1 + 1, zmd > 0 ? zmd : 0, 0, 1, 0);
-            b = true;
-          }
+    // Two loops instead of one.  A zombie next to a human punches and draws nothing (G:664-677); every other zombie draws
+    // and may move (G:678-690).  The two kinds do not see each other's effects: punches land on human cells — never a
+    // move's target, which must show '.' — and take bullet slots, which movers do not; movers change zombie cells, which
+    // punches do not look at; and who is next to a human is fixed for the phase (humans stand still, a zombie acts from
+    // where it started).  So the punches of all such zombies, in slot order, can come first, and the draw loop — the hot
+    // one: the reference's draw order is its slot order — carries neither their code nor the tests for it.
+    const uint64_t todo = zm & ~skip;  // `if(themap[i][j][k].s[2]) continue;`
+    uint64_t nearm = W::ballot(hnear != 0u) & todo;
+    uint64_t falls = 0ull;  // "near" by the packed compare but no human there (row-end aliasing): they draw like the others
+    while (nearm) {
+      const uint32_t z = (uint32_t)W::ctz64(nearm);
+      const uint64_t bit = nearm & (0ull - nearm);
+      nearm ^= bit;
+      // exact neighbour scan (the packed compare above can alias across a row end; this cannot)
+      const uint32_t q0 = W::readlane(zq, z);
+      const int f = pos_f(q0), r = pos_r(q0), c = pos_c(q0);
+      const int zmd = (int)W::readlane(S.zmd, z);
+      const uint32_t hn = W::readlane(hnear, z);
+      bool b = false;
+      for (int i1 = 0; i1 < 4; ++i1) {
+        if (!((hn >> i1) & 1u)) continue;
+        const int rr = r + DX(i1), cc = c + DY(i1);
+        if (!inmap(p, rr, cc)) continue;
+        const uint32_t q = pos_pack(f, rr, cc);
+        if (use_bm || human_at(S, q) >= 0) {
+          int index = b_ind(S, p);
+          if (refbullet_at(S, q) < 0 && index != -1)  // Zombie::punch CH:838-844
+            bullet_put(S, index, q, i1 + 1, zmd > 0 ? zmd : 0, 0, 1, 0);
+          b = true;
         }
-        if (b) continue;
       }
+      if (!b) falls |= bit;
+    }
+    uint64_t movers = (todo & ~W::ballot(hnear != 0u)) | falls;
+    while (movers) {
+      const uint32_t z = (uint32_t)W::ctz64(movers);
+      movers &= movers - 1ull;
       if (draw(S, lds, p) % 5u < 2u) continue;
       const uint32_t fb = W::readlane(freebits, z);
       const uint32_t zp = W::readlane(S.zpos, z);
       SF_NOUNROLL for (int i1 = 0; i1 < 2; ++i1) {
-        const uint32_t i2 = draw(S, lds, p) % 4u;
+        const uint32_t i2 = draw(S, lds, p) & 3u;
         if (!((fb >> i2) & 1u)) continue;
-        const uint32_t q = (zp & POS_MASK) + (i2 == 0u ? 1024u : i2 == 1u ? 1u : i2 == 2u ? 0u - 1024u : 0u - 1u);
+        // +1024, +1, -1024, -1 for directions 0..3 (DX / DY), out of one packed constant: no branches
+        const uint32_t q = (zp & POS_MASK) + (uint32_t)(int32_t)(int16_t)(0xFFFFFC0000010400ull >> (i2 * 16u));
         // a human cannot be there: a zombie with a human neighbour never reaches this point
-        if (zombie_at(S, q) >= 0) continue;
+        if (W::ballot((S.zpos & (ZF_ALIVE | POS_MASK)) == (ZF_ALIVE | q)) != 0ull) continue;
         W::setlane(S.zpos, z, (zp & ~POS_MASK) | q);
         break;
       }
