@@ -529,7 +529,7 @@ struct Core {
     while (movers) {
       const uint32_t z = (uint32_t)W::ctz64(movers);
       movers &= movers - 1ull;
-      if (draw(S, lds, p) % 5u < 2u) continue;
+      if (mod5(draw(S, lds, p)) < 2u) continue;
       const uint32_t fb = W::readlane(freebits, z);
       const uint32_t zp = W::readlane(S.zpos, z);
       SF_NOUNROLL for (int i1 = 0; i1 < 2; ++i1) {
@@ -1074,14 +1074,26 @@ struct Core {
   }
 
   // human_rnpc_bot G:1927-1940
-  static SF_DEV uint32_t human_rnpc_bot(Arena &S, const uint8_t *lds, const Params &p) {
+  // x % 5 and x % 7 for a draw (x < 1024): multiply-shift quotients that are exact on that range (checked for every x),
+  // four scalar instructions where the compiler's general 32-bit form takes seven
+  static SF_DEV uint32_t mod5(uint32_t x) { return x - ((x * 205u) >> 10) * 5u; }
+  static SF_DEV uint32_t mod7(uint32_t x) { return x - ((x * 1171u) >> 13) * 7u; }
+  // the command tables of G:1929,1936,1939 as packed constants (char k in bits 8k..8k+7): a shift and a mask in scalar
+  // registers instead of a byte load from constant memory on every NPC's path
+  static constexpr uint64_t pack8(const char *t, int n) {
+    uint64_t v = 0;
+    for (int k = 0; k < n; ++k) v |= (uint64_t)(uint8_t)t[k] << (8 * k);
+    return v;
+  }
+  static SF_DEV uint32_t human_rnpc_bot(Arena &S, const uint8_t *lds, const Params &p, bool pick_weapon) {
     // every path starts with one draw; the non-'x' path always draws twice more (G:1928-1939)
+    constexpr uint64_t T_WEAPON = pack8("cvbnm,./", 8), T_MOVE = pack8("12awsdp", 7), T_MISC = pack8("+ufghj[]", 8);
     const uint32_t d1 = draw(S, lds, p);
-    if (S.frame % 50 <= 1) return (uint32_t)("cvbnm,./"[d1 % 8u]);
-    if (d1 % 5u < 3u) return 'x';
+    if (pick_weapon) return (uint32_t)(T_WEAPON >> ((d1 & 7u) * 8u)) & 255u;  // frame % 50 <= 1
+    if (mod5(d1) < 3u) return 'x';
     const uint32_t d2 = draw(S, lds, p);
     const uint32_t d3 = draw(S, lds, p);
-    return d2 % 5u < 3u ? (uint32_t)("12awsdp"[d3 % 7u]) : (uint32_t)("+ufghj[]"[d3 % 8u]);
+    return mod5(d2) < 3u ? (uint32_t)(T_MOVE >> (mod7(d3) * 8u)) & 255u : (uint32_t)(T_MISC >> ((d3 & 7u) * 8u)) & 255u;
   }
 
   // human_action G:965-1012.  S.hcmd holds this step's external commands on lanes < n_agents.
@@ -1133,10 +1145,11 @@ struct Core {
       const P ext = ((S.hfl & (HF_REMOTE | HF_CTRL)) != 0u) | (W::lane() == (uint32_t)p.ind);
       S.hcmd = W::select(ext, S.hcmd, V((uint32_t)'+'));
       uint64_t m = alive & ~(1ull << p.ind) & W::ballot((S.hfl & (HF_RNPC | HF_REMOTE)) == HF_RNPC);
+      const bool pick_weapon = m && S.frame % 50 <= 1;  // the same for every NPC of this sweep
       while (m) {
         const uint32_t i = (uint32_t)W::ctz64(m);
         m &= m - 1ull;
-        W::setlane(S.hcmd, i, human_rnpc_bot(S, lds, p));
+        W::setlane(S.hcmd, i, human_rnpc_bot(S, lds, p, pick_weapon));
       }
     }
     SF_STAMP(S, 9);

@@ -137,6 +137,10 @@ inline int validate(const sf_config *c) {
     return fail(SF_ERR_ARG, "Solo/Timer have exactly one agent");
   if (c->n_agent_profiles != 0 && c->n_agent_profiles != c->n_agents)
     return fail(SF_ERR_ARG, "n_agent_profiles must be 0 or n_agents");
+  // per-player records are what the players of a lock-step match exchange (gameplay.hpp:120-151): Battle mode only.  In
+  // Solo / Timer / Squad every commanded human is built from `player` (Squad team mates from `npc`, gameplay.hpp:1878)
+  if (c->n_agent_profiles != 0 && c->mode != SF_MODE_BATTLE)
+    return fail(SF_ERR_ARG, "agent_profile[] is for SF_MODE_BATTLE (one record per player of the match)");
   const sf_profile *pr[2 + SF_MAX_AGENTS] = {&c->player, &c->npc};
   for (int i = 0; i < c->n_agent_profiles; ++i) pr[2 + i] = &c->agent_profile[i];
   for (int k = 0; k < 2 + c->n_agent_profiles; ++k) {

@@ -156,7 +156,9 @@ struct WaveGfx950 {
   }
   static SF_DEV V rng_commit(V rl, uint32_t e, V la) {
     uint32_t t;
-    asm(
+    // (volatile: the block also raises the wave's priority; its partner in rng_reduce lowers it again, and neither may be
+    // dropped, duplicated or moved across the other)
+    asm volatile(
 #if SF_RNG_PRIO
         "s_setprio " SF_STR(SF_RNG_PRIO_LEVEL) "\n\t"
 #endif
@@ -176,7 +178,7 @@ struct WaveGfx950 {
   // instruction takes no literal on gfx9, and scalar registers are the scarcer kind in this kernel).
   static SF_DEV V rng_reduce(V d, V us, V bias) {
     uint32_t x;
-    asm("v_mad_i32_i24 %[x], %[d], %[us], %[bias]\n\t"
+    asm volatile("v_mad_i32_i24 %[x], %[d], %[us], %[bias]\n\t"
         "s_nop 1\n\t"
         "v_add_u32_dpp %[x], %[x], %[x] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
