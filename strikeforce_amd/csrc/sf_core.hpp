@@ -157,6 +157,12 @@ struct Core {
 #endif
     SF_PROF(PH_RNG);
     S.jomle += 1u;
+    if constexpr (W::FUSED_ROUND) {  // the same round as below, as two asm blocks around the LDS lookups (wave_gfx950.hpp)
+      uint32_t out;
+      const V off = W::rng_round(S.rl, S.jomle, S.la, S.rseed, S.rus, V(SUM_BIAS_LANE), S.xt, out);
+      S.la = W::gload_u16_at(log_base(p), off);
+      return out;
+    }
     // rotate left, new value last (+ copy on 18).  Neither jomle nor the product is reduced mod 2^16: every consumer of
     // the hot state — the 24-bit multiply by the seed, the table offsets, store() — takes the low 16 bits itself
     S.rl = W::rng_commit(S.rl, S.jomle, S.la);

@@ -268,6 +268,8 @@ struct WaveEmu {
     return r;
   }
   static void rng_prio_end() {}
+  static constexpr bool FUSED_ROUND = false;  // (the fused asm form of the round exists on the device only)
+  static V rng_round(V &, uint32_t, V, V, V, V, const uint32_t *, uint32_t &) { return V(0u); }
   static V rng_commit(const V &rl, uint32_t e, const V &la) {
     EMU_OP();
     V r;
