@@ -504,6 +504,7 @@ struct Core {
     // punches do not look at; and who is next to a human is fixed for the phase (humans stand still, a zombie acts from
     // where it started).  So the punches of all such zombies, in slot order, can come first, and the draw loop — the hot
     // one: the reference's draw order is its slot order — carries neither their code nor the tests for it.
+    SF_STAMP(S, 13);  // (diagnostic build: the pre-computation above is charged to its own phase)
     const uint64_t todo = zm & ~skip;  // `if(themap[i][j][k].s[2]) continue;`
     uint64_t nearm = W::ballot(hnear != 0u) & todo;
     uint64_t falls = 0ull;  // "near" by the packed compare but no human there (row-end aliasing): they draw like the others

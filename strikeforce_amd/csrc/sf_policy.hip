@@ -1,14 +1,3 @@
-  // 32-column tile) of six MFMAs.  The W fragments of group n + 1 are read behind the first MFMA of group n; behind
-  // the second MFMA of group 3 comes the unit's barrier (the loaders have filled the other stage, every compute wave
-  // has read this one) and the read of the next unit's A fragments.  sched_barrier pins the order; ten groups make one
-  // period of the fragment slots, so the loop body is two units.  (Tried instead of the barrier: FULL / FREE counters in
-  // LDS, two and three stages — the compute waves then poll for the loaders, 8 % slower; tools/experiments.)
-  // ----------------------------------------------------------------------------------------------------------
-  // 32-column tile) of six MFMAs.  The W fragments of group n + 1 are read behind the first MFMA of group n; behind
-  // the second MFMA of group 3 comes the unit's barrier (the loaders have filled the other stage, every compute wave
-  // has read this one) and the read of the next unit's A fragments.  sched_barrier pins the order; ten groups make one
-  // period of the fragment slots, so the loop body is two units.
-  // ----------------------------------------------------------------------------------------------------------
 // sf_policy.hip — batched on-device evaluation of the reference's bot network.
 //
 // What is computed, per agent, is AgentModel::forward of StrikeForce-client/bots/bot-0.5/Modules.hpp:54-179:
