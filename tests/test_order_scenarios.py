@@ -118,6 +118,27 @@ IMPLS = [pytest.param(Oracle, id="oracle"), pytest.param(Emu, id="emu"), pytest.
 IMPLS_REF = IMPLS + [pytest.param("reference", id="reference", marks=needs_ref)]
 
 
+def ref_player():
+    """the level-10 account (15000 Hp): survives whatever the yard throws at it for 80 steps"""
+    import ref_cases
+    return list(ref_cases.RICH)
+
+
+def phase_draws(s):
+    """draws of the last step by phase [zombie_action, update_bull, human_action, update_bull, spawns, rest]: from the
+    oracle / the reference driver; the emulator and the device have no such counter (the step's total is in jomle)"""
+    if isinstance(s, RefSim):
+        return s.r.phase_draws
+    if hasattr(s.sim, "phase_draws"):
+        return s.sim.phase_draws(0)
+    pytest.skip("no per-phase draw counter on this implementation")
+
+
+def close(s):
+    if isinstance(s, RefSim):
+        s.r.close()
+
+
 def make(impl, w, tb, player=P300, squad=False):
     return RefSim(w, tb, player, squad) if impl == "reference" else Sim(impl, w, tb)
 
@@ -323,3 +344,71 @@ def test_battle_ends_when_every_rival_is_dead(impl):
     d = s.step("++_")
     assert d.humans[2].alive == 0 and (d.hdr.done, d.hdr.outcome) == (1, abi.WON)
     assert (d.hdr.kills, d.hdr.teams_kills, d.hdr.loot) == (0, 0, 0)
+
+
+# ---- Squad: dead rivals alone do not end the game ------------------------------------------------------------------------
+@pytest.mark.parametrize("impl", IMPLS)
+def test_squad_needs_kills_and_dead_rivals(impl):
+    """Squad ends on `level * 10 <= teams_kills && rivals_are_dead()` (gameplay.hpp:1186).  All five opponents leave by
+    '_' (Hp 0, gameplay.hpp:696-699; nobody's kill: teams_kills stays 0): rivals_are_dead() is true (:497-505) but the
+    game goes on; the player's own death then ends it, lost (:1131)."""
+    w = world(SQUAD_START, abi.MODE_SQUAD, 10)
+    s = make(impl, w, 1700000000)
+    d = s.step("+++++" + "_____")
+    assert [h.alive for h in d.humans[5:10]] == [0] * 5 and [h.alive for h in d.humans[:5]] == [1] * 5
+    assert (d.hdr.teams_kills, d.hdr.done) == (0, 0)
+    d = s.step("+")
+    assert d.hdr.done == 0
+    d = s.step("_")
+    assert (d.hdr.done, d.hdr.outcome) == (1, abi.DIED)
+
+
+# ---- the NPC policy's draw paths ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("impl", IMPLS_REF)
+def test_npc_humans_draw_one_or_three_times_and_pick_weapons_on_the_fiftieth_frame(impl):
+    """Solo, level 3, three open floors.  The first NPC human is spawned at the very first loop top (frame 1,
+    gameplay.hpp:1448-1449,559-572: three coordinate draws, no fourth; team 0, Hp 1000 at any level — the level-ups of
+    gen_human raise def_Hp only, Character.hpp:873-888, App. E-6), the next ones at frames 51, 101.  Every step human_action asks human_rnpc_bot for its
+    command (gameplay.hpp:1927-1940) before the sweep draw: on a frame with frame % 50 <= 1 ONE draw picks a weapon,
+    "cvbnm,./"[d % 8] (all eight owned at level 1: obey selects it, vec = 2, ind = d % 8, gameplay.hpp:781-791);
+    otherwise d1 % 5 < 3 -> 'x' after ONE draw, else THREE draws (d2 chooses the table, d3 the entry).  The test walks
+    the generator's known answers (random.hpp:54-62) through every step by hand — zombie_action's share of each step's
+    draws is taken from the implementation under test (it is not what this scenario is about) — and checks the number of
+    draws human_action made in every step and, on the weapon-pick frames, the weapon the NPC holds."""
+    opened = [(f, r, c) for f in range(3) for r in range(1, ROWS - 1) for c in range(1, COLS - 1)]  # three open floors
+    w = world(opened, abi.MODE_SOLO, 1, level=3, player=ref_player(), H=8, Z=16, B=64)
+    tb = 1700000000
+    s = make(impl, w, tb, player=ref_player())
+    d = s.dump()
+    assert sum(h.alive for h in d.humans) == 2, "the frame-1 spawn found a free cell (28 x 98 of 30 x 100 are)"
+    npc = d.humans[1]
+    assert (npc.alive, npc.team, npc.rnpc, npc.hp, npc.mindamage, npc.stamina, npc.way) == (1, 0, 1, 1000, 100, 1000000, 1)
+    k = kat(tb, 6000)
+    picks = threes = 0
+    for step in range(0, 85):
+        before = d.hdr.jomle - 18 - 1024           # draws made so far
+        frame_in_human_action = d.hdr.frame + 1    # the first half-tick's ++frame has happened (gameplay.hpp:1460)
+        npcs = [i for i, h in enumerate(d.humans) if i != 0 and h.alive and h.rnpc]
+        alive_before = sum(h.alive for h in d.humans)
+        d = s.step("+")
+        if sum(h.alive for h in d.humans) < alive_before or not d.humans[0].alive:
+            break                                  # somebody died in this step: who was still asked is not visible from outside
+        za = phase_draws(s)[0]                      # zombie_action's draws of this step (not under test here)
+        i = before + za + 1                         # + the first update_bull's draw: index of the first NPC's first draw
+        want = 0
+        for slot in npcs:                           # slot order, gameplay.hpp:985
+            d1 = k[i]
+            if frame_in_human_action % 50 <= 1:
+                n = 1
+                picks += 1
+                assert (d.humans[slot].vec, d.humans[slot].ind) == (2, d1 % 8), (step, slot)
+            elif d1 % 5 < 3:
+                n = 1
+            else:
+                n = 3
+                threes += 1
+            i += n
+            want += n
+        assert phase_draws(s)[2] == want + 1, (step, npcs, phase_draws(s))   # + the sweep-direction draw
+    assert picks >= 1 and threes >= 5 and step >= 60
+    close(s)
