@@ -210,7 +210,9 @@ struct WaveGfx950 {
     const uint32_t base = (uint32_t)(uintptr_t)(lptr)xt;
     uint32_t t, m, oa, ob;
     asm volatile(
+#if SF_RNG_PRIO
         "s_setprio " SF_STR(SF_RNG_PRIO_LEVEL) "\n\t"
+#endif
         "v_mul_u32_u24 %[t], %[e], %[la]\n\t"
         "s_mov_b64 vcc, 0x60000\n\t"
         "v_cndmask_b32_dpp %[rl], %[rl], %[t], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -240,8 +242,10 @@ struct WaveGfx950 {
         "s_nop 1\n\t"
         "v_add_u32_dpp %[x], %[x], %[x] row_bcast:15 row_mask:0x2 bank_mask:0xf\n\t"
         "v_sub_u32_sdwa %[x], %[x], %[x] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
-        "v_lshl_add_u32 %[x], %[x], 1, %[bias]\n\t"
-        "s_setprio 0"
+        "v_lshl_add_u32 %[x], %[x], 1, %[bias]"
+#if SF_RNG_PRIO
+        "\n\ts_setprio 0"
+#endif
         : [pr] "=&v"(pr), [d] "=&v"(d), [x] "=&v"(x), [o] "=&s"(o), [sg] "=&s"(sg)
         : [a] "v"(a), [b] "v"(b), [us] "v"(us), [bias] "v"(bias)
         : "scc");

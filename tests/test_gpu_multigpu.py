@@ -22,6 +22,7 @@ def test_results_allgather_through_the_c_abi_one_rank():
     g.set_stream(torch.cuda.current_stream().cuda_stream)
     g.reset(*w.seeds())
     g.comm_init(env.ArenaBatch.comm_unique_id(), 0, 1)
+    assert g.comm_ranks() == 1  # ncclCommCount of the library's communicator (sf_comm_ranks)
     cmds, _ = config.bench_commands(64, 1, 600)
     d = torch.from_numpy(cmds).cuda()
     out = [torch.full((64 * 8,), -7, dtype=torch.int32, device="cuda") for _ in range(2)]
@@ -50,3 +51,5 @@ def test_bench_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5
     assert d["value"] > 0 and d["scaling"] == "weak"
     assert "configs[2]" in d["config"]["workload"]
+    assert "rccl_ranks" in d and d["rccl_ranks"] is None  # (gloo rehearsal: no RCCL communicator; a real run reports N)
+    assert d["repeats"]["n"] == 21                         # a 20-step region is short: median of 21 repeats

@@ -128,3 +128,27 @@ def test_squad_agents_observe_and_die_as_in_the_reference(impl):
 def _gpu_dump(g):
     from oracle_lib import ArenaDump
     return ArenaDump(*g.dump_raw(0))
+
+
+@pytest.mark.gpu
+def test_device_resident_forms_of_the_new_entry_points():
+    """sf_step_end_device (commands already in HBM) and sf_agent_alive_device against their host forms."""
+    import torch
+    from strikeforce_amd import env
+    A = 8
+    w1, w2 = config.baseline_workload("C5", arenas=A), config.baseline_workload("C5", arenas=A)
+    a, b = env.ArenaBatch(w1), env.ArenaBatch(w2)
+    a.reset(*w1.seeds()), b.reset(*w2.seeds())
+    n = w1.cfg.n_agents
+    cmds, _ = config.bench_commands(A, n, 120)
+    d = torch.from_numpy(cmds).cuda()
+    alive = torch.zeros(A * n, dtype=torch.uint8, device="cuda")
+    for s in range(120):
+        a.step(cmds[s])
+        b.step_begin()
+        b.step_end_device(d.data_ptr() + s * A * n)
+        if s % 10 == 0:
+            b.agent_alive_device(alive.data_ptr())
+            b.synchronize()
+            assert (alive.cpu().numpy().reshape(A, n) == a.agent_alive()).all()
+    assert (a.digest() == b.digest()).all()
