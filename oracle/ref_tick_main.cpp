@@ -29,6 +29,7 @@
 //   reset_native                    setup() with the seeds it makes itself (time(), libc rand: gameplay.hpp:1233,1745-1747)
 //                                   or, in replay mode, reads from the sample; answers "ok <tb> <serial>"
 //   logclose                        closes the log; answers its path (relative to the working directory)
+//   rivals                          gameplay::rivals_are_dead() (gameplay.hpp:497-505), the one helper of check_end that is in the build
 //   bench <steps> <seed>            timing (bench.py's cpu_baseline): `steps` iterations under the 28-command random agent
 //                                   of SURVEY §8d (LCG x <- 1664525 x + 1013904223, command (x >> 16) % 28); when the
 //                                   player is dead the game is set up again with tb + 1 (check_end is not in the build)
@@ -284,6 +285,8 @@ int main() {
                 printf("ok %lld %lld %d %d %d %d\n", client.tb, g.serial_number, ind, client.n, client.team, (int)disconnect);
             else
                 printf("ok %lld %lld\n", (long long)g.tb, g.serial_number);
+        } else if (s == "rivals") {
+            printf("ok %d\n", (int)g.rivals_are_dead());
         } else if (s == "logclose") {
             g.log_file.close();
             printf("ok %s\n", g.log_filename.c_str());

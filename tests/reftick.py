@@ -149,6 +149,9 @@ class RefTick:
             t = r[-1].split()[1:]
         return int(t[0]), int(t[1])
 
+    def rivals_are_dead(self):
+        return bool(int(self._cmd("rivals")[0].split()[1]))
+
     def logclose(self):
         r = self._cmd("logclose")
         return os.path.join(self.dir, r[0].split(" ", 1)[1])
