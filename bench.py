@@ -509,13 +509,21 @@ def main():
         conv0_fma = float((nwin(yy) * nwin(xx) * ok).sum()) * 160.0
         nonzeros = float(np.minimum(n_cnt, SP_CAP).sum())
         # the same forward on a second parameter set: weights 4x the default initialisation (saturating gates, peaked
-        # softmax — the shape a trained checkpoint has, which a fresh initialisation lacks); operands change clocks
+        # softmax — the shape a trained checkpoint has, which a fresh initialisation lacks); operands change clocks —
+        # and on the layered form of the convolution stack (SF_POLICY_LAYERED=1: conv0 on the non-zeros, conv1 / conv2 as
+        # bf16-split products, conv3 in k_tail), the cross-check path, for the comparison
         pb4 = policy.PolicyBatch(policy.init_parameters(seed=3, gain=4.0), agents, device=local)
         pb4.set_stream(torch.cuda.current_stream().cuda_stream)
+        os.environ["SF_POLICY_LAYERED"] = "1"
+        try:
+            pbl = policy.PolicyBatch(policy.init_parameters(seed=0), agents, device=local)
+        finally:
+            del os.environ["SF_POLICY_LAYERED"]
+        pbl.set_stream(torch.cuda.current_stream().cuda_stream)
         ev4 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         fwd = lambda q: q.forward_sparse(d_keys.data_ptr(), d_vals.data_ptr(), d_counts.data_ptr(), d_pov.data_ptr(), SP_CAP, agents,
                                          d_probs.data_ptr(), d_value.data_ptr(), d_dense_ptr=d_fallback.data_ptr())
-        for q in (pb, pb4):
+        for q in (pb, pb4, pbl):
             fwd(q), fwd(q)
         ev4[0].record()
         for _ in range(5):
@@ -524,11 +532,16 @@ def main():
         for _ in range(5):
             fwd(pb4)
         ev4[2].record()
+        for _ in range(5):
+            fwd(pbl)
+        ev4[3].record()
         torch.cuda.synchronize()
         pb4.close()
+        pbl.close()
         pol = {"sparse_overflows": sp_over, "dense_fallback_agents_last_step": sp_fallback, "loop_ms": pe[0].elapsed_time(pe[1]) / pol_n,
                "by_kernel": [(m / pol_n, f / pol_n, n // pol_n) for (m, f, n) in by_k], "conv0_fma": conv0_fma, "nonzeros": nonzeros,
                "forward_ms_default_init": ev4[0].elapsed_time(ev4[1]) / 5, "forward_ms_gain4": ev4[1].elapsed_time(ev4[2]) / 5,
+               "forward_ms_layered": ev4[2].elapsed_time(ev4[3]) / 5,
                "steps": pol_n, "agents": agents}
         pb.close()
 
@@ -604,39 +617,40 @@ def main():
         if pol:
             (g_ms, g_fl, g_n), (b_ms, b_fl, b_n), (c_ms, _c_fl, c_n), (t_ms, t_fl, t_n) = pol["by_kernel"]
             tf = lambda fl, ms: fl / (ms / 1e3) / 1e12 if ms > 0 else 0.0
-            b3_useful, b3_exec = tf(b_fl, b_ms), 6.0 * tf(b_fl, b_ms)
-            act0_bytes = pol["agents"] * 15 * 15 * 160 * 4 + pol["nonzeros"] * 8  # conv0's output tile + the lists it reads
+            nz_agent = pol["nonzeros"] / max(1, pol["agents"])
+            # k_feat_list: per non-zero one 640-byte row of the composed matrix F (21 MB: served by the L2s / the infinity
+            # cache, so this is not HBM traffic) + the 8-byte list entry; per agent the 640-byte result
+            feat_bytes = pol["nonzeros"] * (640 + 8) + pol["agents"] * 640
+            feat_row = {"ms_per_forward": c_ms, "bound": "hbm", "achieved": feat_bytes / (c_ms / 1e3) / 1e9 if c_ms > 0 else 0.0,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (feat_bytes / (c_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if c_ms > 0 else 0.0,
+                        "algorithmic_bytes": feat_bytes, "useful_gflop": 2.0 * pol["nonzeros"] * 160 / 1e9,
+                        "what": "the four bias-free convolutions (Modules.hpp:66-71: nothing between them) as ONE matrix, composed at "
+                                "sf_policy_create, applied to the %.0f non-zeros per agent: one 640-byte row of it per non-zero, f64 "
+                                "accumulation; the rows come out of the L2s / infinity cache (the matrix is 21 MB), the figure is "
+                                "those gathered bytes against the HBM peak" % nz_agent}
+            tail_row = {"ms_per_forward": t_ms, "bound": "mfma", "achieved": tf(t_fl, t_ms), "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": tf(t_fl, t_ms) / MFMA_F32_PEAK_TFLOPS,
+                        "what": "both GRU cells + combined_processor + 6 ResB layers + heads, f32 MFMA"}
+            dom = dict(feat_row if c_ms >= t_ms else tail_row)
+            dom["kernel"] = "k_feat_list" if c_ms >= t_ms else "k_tail"
+            dom.pop("what", None)
             out["policy"] = {
                 "what": "per rank: observe (as the list of non-zero floats) -> bot-0.5 network (f32 results, random-init weights; "
-                        "conv0 on those non-zeros, conv1/conv2 as bf16 hi/mid/lo split products on the bf16 MFMA, everything behind "
-                        "conv2 in one kernel on the f32 MFMA) -> sample -> K=1 step -> memory reset of restarted games, all on "
-                        "device, %d steps; agents evaluated on a blank window: %d (lists that do not fit are redone from a dense "
-                        "fallback on the device; %d agents took it in the last step)"
+                        "the convolution stack — four bias-free convolutions with nothing between them — as one composed matrix on "
+                        "those non-zeros, everything behind it in one kernel on the f32 MFMA) -> sample -> K=1 step -> memory reset "
+                        "of restarted games, all on device, %d steps; agents evaluated on a blank window: %d (lists that do not fit "
+                        "are redone from a dense fallback on the device; %d agents took it in the last step)"
                         % (pol["steps"], pol["sparse_overflows"], pol["dense_fallback_agents_last_step"]),
                 "agent_steps_per_s": world * pol["agents"] / (pol["loop_ms"] / 1e3), "ms_per_step": pol["loop_ms"],
                 "forward_ms": {"default_init": pol["forward_ms_default_init"], "weights_x4": pol["forward_ms_gain4"],
-                               "what": "the forward alone (4 kernels + 2 fix-ups) on the last step's lists: libtorch's default "
-                                       "initialisation, and weights 4x that (saturated gates: a trained checkpoint's operand shape)"},
-                # dominant kernel: k_gemm_b3 (conv1, conv2: 92 % of the matrix work).  `frac` prices USEFUL work — the
-                # f32-equivalent 2MNK — against the dense bf16 peak; the kernel executes six bf16 products per useful one,
-                # `mfma_pipe_busy` is that executed rate against the same peak (pipe utilisation, not a roofline fraction)
-                "roofline": {"bound": "mfma", "achieved": b3_useful, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": b3_useful / MFMA_BF16_PEAK_TFLOPS,
-                             "kernel": "k_gemm_b3 (%d launches per forward: conv1, conv2), useful flop = 2MNK f32-equivalent" % b_n,
-                             "ms_per_forward": b_ms, "mfma_pipe_busy": b3_exec / MFMA_BF16_PEAK_TFLOPS,
-                             "bf16_tflops_executed": b3_exec, "vs_f32_mfma_peak": b3_useful / MFMA_F32_PEAK_TFLOPS},
-                "kernels": {
-                    "k_conv0_sparse": {"ms_per_forward": c_ms, "bound": "hbm", "achieved": act0_bytes / (c_ms / 1e3) / 1e9 if c_ms > 0 else 0.0,
-                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (act0_bytes / (c_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if c_ms > 0 else 0.0,
-                                       "algorithmic_bytes": act0_bytes, "useful_gflop": 2.0 * pol["conv0_fma"] / 1e9,
-                                       "what": "first convolution on the %.0f non-zeros per agent; algorithmic bytes = its 15x15x160 f32 output "
-                                               "tile per agent + the lists" % (pol["nonzeros"] / max(1, pol["agents"]))},
-                    "k_tail": {"ms_per_forward": t_ms, "bound": "mfma", "achieved": tf(t_fl, t_ms), "peak": MFMA_F32_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": tf(t_fl, t_ms) / MFMA_F32_PEAK_TFLOPS,
-                               "what": "conv3 + both GRU cells + combined_processor + 6 ResB layers + heads, f32 MFMA"},
-                    "k_gemm_f32_other": {"ms_per_forward": g_ms, "launches": g_n, "achieved": tf(g_fl, g_ms), "peak": MFMA_F32_PEAK_TFLOPS,
-                                         "unit": "TFLOP/s"}},
-                "flop_per_agent_forward": (g_fl + b_fl + t_fl) / pol["agents"],
+                               "layered": pol["forward_ms_layered"],
+                               "what": "the forward alone (2 kernels) on the last step's lists: libtorch's default initialisation, "
+                                       "weights 4x that (saturated gates: a trained checkpoint's operand shape), and the layered "
+                                       "cross-check form of the convolution stack (SF_POLICY_LAYERED=1: 48.6 MFLOP per agent, "
+                                       "conv1 / conv2 as bf16-split products on the bf16 MFMA — round 2's path)"},
+                "roofline": dom,
+                "kernels": {"k_feat_list": feat_row, "k_tail": tail_row},
+                "flop_per_agent_forward": 2.0 * nz_agent * 160 + (g_fl + b_fl + t_fl) / pol["agents"],
             }
         if world == 1 and not args.no_other_configs:
             out["other_configs"] = other_configs(args, local, torch, config, env, args.workload)

@@ -863,6 +863,209 @@ __global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const f
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The convolution stack folded into one matrix.
+//
+// GameCNN::forward (Modules.hpp:66-71) is conv3(conv2(conv1(conv0(x)))): four bias-free convolutions with nothing in
+// between, i.e. one LINEAR map of the 32 x 31 x 31 observation onto the 160 features `feat`.  sf_policy_create composes
+// the four weight tensors once (k_fold: the transposed convolutions applied to conv3's 160 output rows, in f64 on the
+// device) into that map's matrix F [row = x << 10 | y << 5 | channel][160] f32 — 21 MB, which stays in the L2s / the
+// infinity cache — and a forward pass is
+//     feat = sum over the observation's non-zero floats of  value * F[row]          (~300 of 30 752 are non-zero)
+// 0.1 MFLOP per agent instead of 48.6: the 15x15, 7x7 and 3x3 activations never exist, and neither do the three
+// largest kernels of the layered path (k_conv0_sparse, two k_gemm_b3 launches), which stays in the library behind
+// SF_POLICY_LAYERED=1 as the cross-check that evaluates the layers in the reference's order.
+// Arithmetic: every product and sum in f64 (exact products of two f32; the f64 sum of a few hundred terms rounds far
+// below f32), in the observation's scan order, one partial sum per pair of channels, the partial sums of the non-empty
+// pairs added in channel order, one rounding to f32 at the end.  List form and dense form follow the same order, so
+// their results are the same bits; against the reference's layer-by-layer f32 evaluation the difference is the
+// reference's own rounding (F's entries are within half an ulp of the exact composition).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FD_ROWS = 32 * 32 * 32;  // rows of F: x (5 bits), y (5 bits), channel (5 bits); x, y = 31 unused
+constexpr int FD_G = OBS_C / 2;        // partial sums: one per pair of channels
+constexpr int FD_SEG = 2 * OBS_W * OBS_W;  // floats of the dense observation behind one partial sum
+
+// one transposed 3x3 / stride-2 convolution: Tout[o][y][x][cin] = sum over taps (ky, kx) with (y - ky, x - kx) even and
+// inside, and over c:  Tin[o][(y - ky) / 2][(x - kx) / 2][c] * W[c][cin][ky][kx].  W is torch's [c][cin][3][3] (perm 0)
+// or this file's [c][tap][cin] (perm 1).
+__global__ __launch_bounds__(256) void k_fold(const double *Tin, const float *W, double *Tout, int So, int S, int C, int Cin, int perm) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)HID * S * S * Cin) return;
+  const int cin = (int)(i % Cin);
+  size_t r = i / Cin;
+  const int x = (int)(r % S);
+  r /= S;
+  const int y = (int)(r % S), o = (int)(r / S);
+  double acc = 0.0;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = y - ky;
+    if (ty < 0 || (ty & 1) || (ty >> 1) >= So) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = x - kx;
+      if (tx < 0 || (tx & 1) || (tx >> 1) >= So) continue;
+      const double *tin = Tin + (((size_t)o * So + (ty >> 1)) * So + (tx >> 1)) * C;
+      const int tap = ky * 3 + kx;
+      for (int c = 0; c < C; ++c)
+        acc += tin[c] * (double)(perm ? W[((size_t)c * 9 + tap) * Cin + cin] : W[((size_t)c * Cin + cin) * 9 + tap]);
+    }
+  }
+  Tout[i] = acc;
+}
+__global__ __launch_bounds__(256) void k_to_f64(const float *src, double *dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (double)src[i];
+}
+// T0 [o][y][x][channel] f64 -> F [x << 10 | y << 5 | channel][o] f32
+__global__ __launch_bounds__(256) void k_fold_out(const double *T0, float *F) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)OBS_W * OBS_W * OBS_C * HID) return;
+  const int o = (int)(i % HID);
+  size_t r = i / HID;
+  const int ch = (int)(r % OBS_C);
+  r /= OBS_C;
+  const int x = (int)(r % OBS_W), y = (int)(r / OBS_W);
+  F[((size_t)((x << 10) | (y << 5) | ch)) * HID + o] = (float)T0[(((size_t)o * OBS_W + y) * OBS_W + x) * OBS_C + ch];
+}
+
+// list form: one wavefront per agent walks the agent's list, 64 entries per fetch (one per lane, the next 64 requested
+// before these are used); lane l < 40 owns features 4 l .. 4 l + 3 (one 16-byte piece of a row of F), an entry's row and
+// value reach all lanes by v_readlane, eight rows are requested before the first is used.
+__global__ __launch_bounds__(64) void k_feat_list(const float *__restrict__ F, float *__restrict__ feat, int agents, C0List li) {
+  const int b = (int)blockIdx.x, l = (int)threadIdx.x;
+  if (b >= agents) return;
+  uint32_t n = li.counts[b];
+  if (n > (uint32_t)C0_LCAP || n > (uint32_t)li.cap) {  // (the 0xffffffff marker of a crowded window too)
+    n = 0u;
+    if (l == 0 && li.overflows) atomicAdd(li.overflows, 1u);  // null: k_feat_dense redoes this agent
+  }
+  const uint32_t *__restrict__ keys = li.keys + (size_t)b * li.cap;
+  const float *__restrict__ vals = li.vals + (size_t)b * li.cap;
+  const float *Fl = F + 4 * (l < HID / 4 ? l : 0);
+  double tot[4] = {0.0, 0.0, 0.0, 0.0}, cur[4] = {0.0, 0.0, 0.0, 0.0};
+  uint32_t g = 0u;
+  uint32_t nkey = (uint32_t)l < n ? keys[l] : 0u;
+  float nval = (uint32_t)l < n ? vals[l] : 0.f;
+  for (uint32_t e0 = 0u; e0 < n; e0 += 64u) {
+    const uint32_t key = nkey;
+    const float val = nval;
+    {
+      const uint32_t e = e0 + 64u + (uint32_t)l;
+      nkey = e < n ? keys[e] : 0u, nval = e < n ? vals[e] : 0.f;
+    }
+    const uint32_t ch = ((key & 511u) * 57u) >> 9;  // the key's low field is 9 * channel
+    const uint32_t rowo = ((((key >> 9) & 1023u) << 5) | ch) * (uint32_t)HID;
+    const uint32_t cnt = n - e0 < 64u ? n - e0 : 64u;
+    constexpr uint32_t U = 8u;
+    for (uint32_t u0 = 0u; u0 < cnt; u0 += U) {
+      f32x4 w4[U];
+#pragma unroll
+      for (uint32_t u = 0u; u < U; ++u) {
+        const uint32_t s = u0 + u < cnt ? u0 + u : cnt - 1u;
+        w4[u] = ldg4(Fl + (uint32_t)__builtin_amdgcn_readlane((int)rowo, (int)s));
+      }
+#pragma unroll
+      for (uint32_t u = 0u; u < U; ++u) {
+        if (u0 + u >= cnt) break;
+        const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)ch, (int)(u0 + u)) >> 1;
+        if (gg != g) {  // the next pair of channels: close the partial sum
+          asm volatile("" ::: "memory");  // (a real branch, taken <= 16 times per agent: not sixteen selects per entry)
+          g = gg;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tot[j] += cur[j], cur[j] = 0.0;
+        }
+        const double v = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), (int)(u0 + u)));
+        cur[0] = fma(v, (double)w4[u].x, cur[0]);
+        cur[1] = fma(v, (double)w4[u].y, cur[1]);
+        cur[2] = fma(v, (double)w4[u].z, cur[2]);
+        cur[3] = fma(v, (double)w4[u].w, cur[3]);
+      }
+    }
+  }
+  if (l < HID / 4) {
+    f32x4 o;
+    o.x = (float)(tot[0] + cur[0]), o.y = (float)(tot[1] + cur[1]), o.z = (float)(tot[2] + cur[2]), o.w = (float)(tot[3] + cur[3]);
+    *reinterpret_cast<f32x4 *>(feat + (size_t)b * HID + 4 * l) = o;
+  }
+}
+
+// dense form: one 16-wave workgroup per agent, wavefront w scans channels 2 w and 2 w + 1 of the observation (its partial
+// sum), the sixteen partial sums meet in LDS.  With li.counts given (the launch behind k_feat_list) only the agents whose
+// list did not fit are done.
+constexpr int FD_T = 64 * FD_G;
+__global__ __launch_bounds__(FD_T) void k_feat_dense(const float *__restrict__ obs, const float *__restrict__ F, float *__restrict__ feat,
+                                                     int agents, C0List li) {
+  __shared__ double part[FD_G][HID];
+  __shared__ uint32_t some[FD_G];
+  const int t = (int)threadIdx.x, w = t >> 6, l = t & 63;
+  auto nxt = [&](int b) {
+    if (li.counts)
+      while (b < agents && !(li.counts[b] > (uint32_t)C0_LCAP || li.counts[b] > (uint32_t)li.cap)) b += (int)gridDim.x;
+    return b;
+  };
+  constexpr int NIT = (FD_SEG + 63) / 64;  // 31 floats per lane
+  const float *Fl = F + 4 * (l < HID / 4 ? l : 0);
+  for (int b = nxt((int)blockIdx.x); b < agents; b = nxt(b + (int)gridDim.x)) {
+    const float *src = obs + (size_t)b * OBS_F + (size_t)w * FD_SEG;
+    float pre[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = k * 64 + l;
+      pre[k] = i < FD_SEG ? __builtin_nontemporal_load(src + i) : 0.f;
+    }
+    double cur[4] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t any = 0u;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      uint64_t m = __builtin_amdgcn_ballot_w64(pre[k] != 0.f);
+      if (!m) continue;
+      any = 1u;
+      const uint32_t idx = (uint32_t)(w * FD_SEG + k * 64 + l);  // = channel * 961 + y * 31 + x
+      const uint32_t chn = idx / (uint32_t)(OBS_W * OBS_W), r = idx - chn * (uint32_t)(OBS_W * OBS_W);
+      const uint32_t y = r / (uint32_t)OBS_W, x = r - y * (uint32_t)OBS_W;
+      const uint32_t row = (x << 10) | (y << 5) | chn;
+      while (m) {  // four non-zeros at a time: their rows of F first, then the sums in scan order
+        f32x4 w4[4];
+        float vv[4];
+        int nt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          w4[q] = f32x4{0.f, 0.f, 0.f, 0.f}, vv[q] = 0.f;
+          if (m) {
+            const int s = __builtin_ctzll(m);
+            m &= m - 1ull;
+            vv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre[k]), s));
+            const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)row, s);
+            w4[q] = ldg4(Fl + (size_t)rw * HID);
+            nt = q + 1;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < nt) {
+            const double v = (double)vv[q];
+            cur[0] = fma(v, (double)w4[q].x, cur[0]);
+            cur[1] = fma(v, (double)w4[q].y, cur[1]);
+            cur[2] = fma(v, (double)w4[q].z, cur[2]);
+            cur[3] = fma(v, (double)w4[q].w, cur[3]);
+          }
+      }
+    }
+    if (l < HID / 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[w][4 * l + j] = cur[j];
+    }
+    if (l == 0) some[w] = any;
+    __syncthreads();
+    if (t < HID) {
+      double tot = 0.0;
+      for (int g = 0; g < FD_G; ++g)
+        if (some[g]) tot += part[g][t];
+      feat[(size_t)b * HID + t] = (float)tot;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Row kernels: one wavefront per agent, lane l owns elements l, l+64, l+128 (< 160) of a 160-vector.
 // ---------------------------------------------------------------------------------------------------------
 __device__ inline float wave_sum(float v) {
@@ -1051,6 +1254,7 @@ static_assert(TL_COMB + TL_R * TL_LDC <= TL_B0 && TL_X1 + TL_R * TL_LD <= TL_B0,
 
 struct TailArgs {
   const float *act2, *obs, *pov, *conv3_w;  // pov: the 160 centre values as a dense row per agent, or null (gather them from obs)
+  const float *feat;                        // the folded convolution stack's output (k_feat_*): conv3 is then not run here
   const float *gru_w_ih[2], *gru_w_hh[2], *gru_b_ih[2], *gru_b_hh[2];
   const float *comb_w, *comb_b;
   const float *res_w[2][3], *res_b[2][3], *head_w[2], *head_b[2];
@@ -1102,9 +1306,11 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
   const int a = valid ? a_raw : t.agents - 1;  // a ragged last workgroup computes its missing rows on the last agent, stores nothing
   // ---- conv3's input (act2 row = 9 pixels x 160 channels, the K order of the permuted weight) and h0
   {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(t.act2 + (size_t)a * (9 * HID));
-    f32x4 *dst = reinterpret_cast<f32x4 *>(tl + TL_A + w * TL_LDX);
-    for (int i = l; i < 9 * HID / 4; i += 64) dst[i] = src[i];
+    if (!t.feat) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(t.act2 + (size_t)a * (9 * HID));
+      f32x4 *dst = reinterpret_cast<f32x4 *>(tl + TL_A + w * TL_LDX);
+      for (int i = l; i < 9 * HID / 4; i += 64) dst[i] = src[i];
+    }
     row_store(tl + TL_B1 + w * TL_LD, l, row_load(t.h[0] + (size_t)a * HID, l));
   }
   // fetched now, used after gru0: the agent's pov (5 cells x 32 channels around the centre of the observation, then the
@@ -1132,7 +1338,8 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     row_store(tl + TL_H1 + w * TL_LD, l, row_load(t.h[1] + (size_t)a * HID, l));
   }
   __syncthreads();
-  if (w < HID / 16) tail_tile<9 * HID>(tl + TL_A, TL_LDX, t.conv3_w, nullptr, tl + TL_Y0, TL_LD, 16 * w, l);  // Modules.hpp:66-71
+  if (t.feat) row_store(tl + TL_Y0 + w * TL_LD, l, row_load(t.feat + (size_t)a * HID, l));
+  else if (w < HID / 16) tail_tile<9 * HID>(tl + TL_A, TL_LDX, t.conv3_w, nullptr, tl + TL_Y0, TL_LD, 16 * w, l);  // Modules.hpp:66-71
   __syncthreads();
   row_store(tl + TL_B0 + w * TL_LD, l, row_norm(row_load(tl + TL_Y0 + w * TL_LD, l)));  // feat_n :108
   __syncthreads();
@@ -1338,6 +1545,8 @@ struct Policy {
   bool f32_conv = false;      // SF_POLICY_F32_CONV=1: conv1, conv2 on the f32 matrix pipe instead (A/B, tests)
   uint32_t *d_overflows = nullptr;  // sf_policy_forward_sparse: agents whose list did not fit since the last query
   bool fused_tail = true;     // SF_POLICY_FUSED_TAIL=0: the layers behind conv2 as 16 separate launches instead (A/B, tests)
+  float *fold = nullptr;      // F: the four convolutions composed into one matrix (k_fold), [FD_ROWS][160]
+  bool folded = true;         // SF_POLICY_LAYERED=1: the four convolutions one after the other instead (cross-check, tests)
   float *conv_w[4] = {}, *gru_w_ih[2] = {}, *gru_w_hh[2] = {}, *gru_b_ih[2] = {}, *gru_b_hh[2] = {};
   float *comb_w = nullptr, *comb_b = nullptr;
   float *res_w[2][3] = {}, *res_b[2][3] = {}, *head_w[2] = {}, *head_b[2] = {};  // [0] policy, [1] value
@@ -1528,6 +1737,31 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
     }
   }
   {
+    // F = conv3 o conv2 o conv1 o conv0 as one matrix (see k_fold): T3 = conv3's rows, then three transposed convolutions
+    const char *e = getenv("SF_POLICY_LAYERED");
+    p->folded = !(e && e[0] == '1');
+    if (p->folded) {
+      double *T[4] = {nullptr, nullptr, nullptr, nullptr};
+      const int side[4] = {31, 15, 7, 3};
+      const size_t elems[4] = {(size_t)HID * 31 * 31 * OBS_C, (size_t)HID * 15 * 15 * HID, (size_t)HID * 7 * 7 * HID, (size_t)HID * 9 * HID};
+      bool ok = true;
+      for (int i = 0; i < 4 && ok; ++i) ok = hipMalloc(reinterpret_cast<void **>(&T[i]), elems[i] * sizeof(double)) == hipSuccess;
+      if (ok) ok = p->dalloc(&p->fold, (size_t)FD_ROWS * HID) == SF_OK;
+      if (ok) {
+        (void)hipMemset(p->fold, 0, (size_t)FD_ROWS * HID * sizeof(float));
+        hipLaunchKernelGGL(k_to_f64, dim3((unsigned)((elems[3] + 255) / 256)), dim3(256), 0, nullptr, p->conv_w[3], T[3], elems[3]);
+        for (int i = 2; i >= 0; --i)  // T[i]: the map from conv i's input to feat
+          hipLaunchKernelGGL(k_fold, dim3((unsigned)((elems[i] + 255) / 256)), dim3(256), 0, nullptr, T[i + 1], p->conv_w[i], T[i],
+                             side[i + 1], side[i], HID, i ? HID : OBS_C, i ? 1 : 0);
+        hipLaunchKernelGGL(k_fold_out, dim3((unsigned)(((size_t)OBS_F * HID + 255) / 256)), dim3(256), 0, nullptr, T[0], p->fold);
+        ok = hipDeviceSynchronize() == hipSuccess;
+      }
+      for (int i = 0; i < 4; ++i)
+        if (T[i]) (void)hipFree(T[i]);
+      if (!ok) SFP_TRY(fail(SF_ERR_DEVICE, "composing the convolution stack failed"));
+    }
+  }
+  {
     const char *e = getenv("SF_POLICY_F32_CONV");
     p->f32_conv = e && e[0] == '1';
     const char *ft = getenv("SF_POLICY_FUSED_TAIL");
@@ -1575,9 +1809,11 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
   SFP_TRY(p->dalloc(&p->h[0], B * HID));
   SFP_TRY(p->dalloc(&p->h[1], B * HID));
   SFP_TRY(p->dalloc(&p->action_input, B * ACT));
-  SFP_TRY(p->dalloc(&p->act[0], B * 225 * HID));
-  SFP_TRY(p->dalloc(&p->act[1], B * 49 * HID));
-  SFP_TRY(p->dalloc(&p->act[2], B * 9 * HID));
+  if (!p->folded) {  // the layered path's activations (181 KB per agent)
+    SFP_TRY(p->dalloc(&p->act[0], B * 225 * HID));
+    SFP_TRY(p->dalloc(&p->act[1], B * 49 * HID));
+    SFP_TRY(p->dalloc(&p->act[2], B * 9 * HID));
+  }
   SFP_TRY(p->dalloc(&p->feat, B * HID));
   SFP_TRY(p->dalloc(&p->feat_n, B * HID));
   SFP_TRY(p->dalloc(&p->gi, B * G3));
@@ -1615,7 +1851,21 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
   hipStream_t st = p->stream;
   // GameCNN                                                                    Modules.hpp:66-71
   const dim3 c0_grid((unsigned)(agents < p->sk_blocks / 2 ? agents : p->sk_blocks / 2));
-  if (li) {
+  if (p->folded) {
+    // the four convolutions as one matrix applied to the non-zeros (k_feat_*), timed as kind 2
+    hipEvent_t e0 = nullptr;
+    if ((rc = p->time_begin(0.0, false, &e0, 2))) return rc;  // useful flop depends on the lists: the caller counts the non-zeros
+    const dim3 fd_grid((unsigned)(agents < 4 * p->sk_blocks ? agents : 4 * p->sk_blocks));
+    if (li) {
+      hipLaunchKernelGGL(k_feat_list, dim3((unsigned)agents), dim3(64), 0, st, p->fold, p->feat, agents, *li);
+      if (e0) SFP_HIP(hipEventRecord(e0, st));
+      if (d_obs)  // redo the agents whose list did not fit from their dense observation (none, normally: the launch is idle)
+        hipLaunchKernelGGL(k_feat_dense, fd_grid, dim3(FD_T), 0, st, d_obs, p->fold, p->feat, agents, *li);
+    } else {
+      hipLaunchKernelGGL(k_feat_dense, fd_grid, dim3(FD_T), 0, st, d_obs, p->fold, p->feat, agents, C0List{});
+      if (e0) SFP_HIP(hipEventRecord(e0, st));
+    }
+  } else if (li) {
     hipEvent_t e0 = nullptr;
     if ((rc = p->time_begin(0.0, false, &e0, 2))) return rc;  // useful flop depends on the lists: the caller counts the non-zeros
     hipLaunchKernelGGL(k_conv0_sparse<true>, c0_grid, dim3(C0_T), C0_LDS, st, (const float *)nullptr, p->conv0_wt, p->act[0], agents, *li);
@@ -1627,15 +1877,18 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
   } else {
     hipLaunchKernelGGL(k_conv0_sparse<false>, c0_grid, dim3(C0_T), C0_LDS, st, d_obs, p->conv0_wt, p->act[0], agents, C0List{});
   }
-  if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, HID, 0, p->conv_w3[1]))) return rc;
-  if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, HID, 0, p->conv_w3[2]))) return rc;
+  if (!p->folded) {
+    if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, HID, 0, p->conv_w3[1]))) return rc;
+    if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, HID, 0, p->conv_w3[2]))) return rc;
+  }
   if (p->fused_tail) {
-    // (timed as one launch on the f32 pipe: conv3 + 4 GRU gate products + combined_processor + 6 ResB layers)
+    // (timed as one launch on the f32 pipe: conv3 unless folded + 4 GRU gate products + combined_processor + 6 ResB layers)
     hipEvent_t e1 = nullptr;
-    if ((rc = p->time_begin(2.0 * agents * ((double)HID * 9 * HID + 4.0 * G3 * HID + (double)HID * COMB_PAD + 6.0 * HID * HID), false, &e1, 3)))
+    if ((rc = p->time_begin(2.0 * agents * ((p->folded ? 0.0 : (double)HID * 9 * HID) + 4.0 * G3 * HID + (double)HID * COMB_PAD + 6.0 * HID * HID), false, &e1, 3)))
       return rc;
     TailArgs t{};
     t.act2 = p->act[2], t.obs = d_obs, t.pov = d_pov, t.conv3_w = p->conv_w[3];
+    t.feat = p->folded ? p->feat : nullptr;
     for (int g = 0; g < 2; ++g) {
       t.gru_w_ih[g] = p->gru_w_ih[g], t.gru_w_hh[g] = p->gru_w_hh[g], t.gru_b_ih[g] = p->gru_b_ih[g], t.gru_b_hh[g] = p->gru_b_hh[g];
       t.h[g] = p->h[g], t.head_w[g] = p->head_w16[g], t.head_b[g] = p->head_b16[g];
@@ -1648,7 +1901,7 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
     if (e1) SFP_HIP(hipEventRecord(e1, st));
     return SF_OK;
   }
-  if ((rc = p->conv(p->act[2], p->conv_w[3], p->feat, agents, 3, HID, 0))) return rc;
+  if (!p->folded && (rc = p->conv(p->act[2], p->conv_w[3], p->feat, agents, 3, HID, 0))) return rc;
   float *const none = nullptr;
   hipLaunchKernelGGL(k_norm, rg, rb, 0, st, p->feat, p->feat_n, none, agents);               // :108
   // gru0 (both gate products in one launch)                                                    :110-113

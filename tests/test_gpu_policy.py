@@ -1,6 +1,11 @@
 """The on-device policy network (include/strikeforce_policy.h, f32 MFMA kernels) against the PyTorch f32 restatement
 of the reference's model (oracle/policy_ref.py).  Floating point: the kernels differ from torch only in summation
-order, so the gate is a relative tolerance, stated per test."""
+order, so the gate is a relative tolerance, stated per test.
+
+Two forms of the convolution stack run here (fixture `cnn`): "folded" — the default: the four bias-free convolutions of
+GameCNN (Modules.hpp:66-71, nothing between them) composed into one matrix at sf_policy_create and applied to the
+observation's non-zeros — and "layered" (SF_POLICY_LAYERED=1): the four convolutions one after the other as the
+reference evaluates them.  Both are held to the same tolerance against the same reference outputs."""
 import os
 import sys
 
@@ -44,7 +49,7 @@ def _memory(pb, B):
 
 
 @pytest.mark.parametrize("B,steps", [(1, 3), (5, 4), (37, 3), (100, 2), (300, 2), (400, 2)])
-def test_forward_matches_reference(B, steps):
+def test_forward_matches_reference(B, steps, cnn):
     """B picks the GEMM variant of each layer: 1-wave, 2-wave and 4-wave blocks, ragged last tiles."""
     rng = np.random.default_rng(B)
     params = policy.init_parameters(seed=B)
@@ -249,10 +254,12 @@ def test_split_and_f32_convolutions_agree():
     out = []
     for f32 in ("0", "1"):
         os.environ["SF_POLICY_F32_CONV"] = f32
+        os.environ["SF_POLICY_LAYERED"] = "1"
         try:
             pb = policy.PolicyBatch(params, B)
         finally:
             del os.environ["SF_POLICY_F32_CONV"]
+            del os.environ["SF_POLICY_LAYERED"]
         d_probs = torch.zeros((B, 9), dtype=torch.float32, device="cuda")
         d_value = torch.zeros(B, dtype=torch.float32, device="cuda")
         for _ in range(2):
@@ -265,7 +272,47 @@ def test_split_and_f32_convolutions_agree():
     assert not np.array_equal(out[0][0], out[1][0])  # two different kernels did run
 
 
-def test_hip_path_reproduces_the_committed_vectors():
+def test_folded_and_layered_convolutions_agree():
+    """The convolution stack as one composed matrix on the non-zeros (default) and layer by layer (SF_POLICY_LAYERED=1) on
+    real observations of the simulator, over recurrent steps: same probabilities, value and state within this file's
+    tolerance; and the folded form's features alone against float64 of the composed map."""
+    A = 64
+    w = config.baseline_workload("C3", arenas=A)
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    n = A * w.cfg.n_agents
+    cmds, _ = config.bench_commands(A, w.cfg.n_agents, 120)
+    params = policy.init_parameters(seed=21)
+    pbs = []
+    for layered in ("0", "1"):
+        os.environ["SF_POLICY_LAYERED"] = layered
+        try:
+            pbs.append(policy.PolicyBatch(params, n))
+        finally:
+            del os.environ["SF_POLICY_LAYERED"]
+    d_obs = torch.zeros((n, 32, 31, 31), dtype=torch.float32, device="cuda")
+    outs = [(torch.zeros((n, 9), dtype=torch.float32, device="cuda"), torch.zeros(n, dtype=torch.float32, device="cuda")) for _ in pbs]
+    differ = False
+    for t in range(6):
+        for s in range(t * 20, (t + 1) * 20):
+            g.step(cmds[s])
+        g.observe_device(d_obs.data_ptr())
+        g.synchronize()
+        for pb, (dp, dv) in zip(pbs, outs):
+            pb.forward(d_obs.data_ptr(), n, dp.data_ptr(), dv.data_ptr())
+            pb.synchronize()
+        np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), rtol=RTOL, atol=ATOL)
+        for b in (0, n // 2, n - 1):
+            np.testing.assert_allclose(pbs[0].get_memory(b)[0], pbs[1].get_memory(b)[0], rtol=RTOL, atol=ATOL * 10)
+        differ = differ or not np.array_equal(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy())
+    assert differ  # two different evaluations did run
+    for pb in pbs:
+        pb.close()
+    g.close()
+
+
+def test_hip_path_reproduces_the_committed_vectors(cnn):
     """tests/golden/policy_vectors.json = outputs of the REFERENCE's AgentModel (bots/bot-0.5/Modules.hpp:26-180
     compiled unedited, oracle/ref_modules.py; generator tests/golden/make_policy_vectors.py): the GPU simulator's
     observations of the same seeded run through the HIP network give the committed probabilities, values and state

@@ -53,7 +53,7 @@ def test_the_list_is_the_dense_observation(which):
     assert np.array_equal(pv.view(np.uint32), want.view(np.uint32))
 
 
-def test_sparse_and_dense_forward_are_bit_identical():
+def test_sparse_and_dense_forward_are_bit_identical(cnn):
     w = config.baseline_workload("C3", arenas=40)
     g = env.ArenaBatch(w)
     g.reset(*w.seeds())
@@ -76,7 +76,7 @@ def test_sparse_and_dense_forward_are_bit_identical():
     assert float(out[0][0].std()) > 0
 
 
-def test_a_list_that_does_not_fit_is_counted():
+def test_a_list_that_does_not_fit_is_counted(cnn):
     w = config.baseline_workload("C2", arenas=8)
     g = env.ArenaBatch(w)
     g.reset(*w.seeds())
@@ -128,7 +128,7 @@ def test_crowded_windows_are_marked_not_truncated():
 
 
 @pytest.mark.parametrize("which,cap,arenas", [("C2", 16, 8), ("C3", 200, 24), ("MAXCAP", 2048, 4)])
-def test_agents_whose_list_does_not_fit_are_evaluated_from_the_dense_fallback(which, cap, arenas):
+def test_agents_whose_list_does_not_fit_are_evaluated_from_the_dense_fallback(which, cap, arenas, cnn):
     """No agent is ever evaluated on a blank window: with sf_observe_overflow_device + sf_policy_forward_sparse_or_dense
     the agents whose list did not fit — a cap far too small (16: every agent), a cap that cuts some lists (200), the
     crowded-window marker (MAXCAP) — are redone from their dense observation on the device, no host round trip.  The
