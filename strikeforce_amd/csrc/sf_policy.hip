@@ -874,11 +874,11 @@ __global__ __launch_bounds__(C0_T) void k_conv0_sparse(const float *obs, const f
 // 0.1 MFLOP per agent instead of 48.6: the 15x15, 7x7 and 3x3 activations never exist, and neither do the three
 // largest kernels of the layered path (k_conv0_sparse, two k_gemm_b3 launches), which stays in the library behind
 // SF_POLICY_LAYERED=1 as the cross-check that evaluates the layers in the reference's order.
-// Arithmetic: every product and sum in f64 (exact products of two f32; the f64 sum of a few hundred terms rounds far
-// below f32), in the observation's scan order, one partial sum per pair of channels, the partial sums of the non-empty
-// pairs added in channel order, one rounding to f32 at the end.  List form and dense form follow the same order, so
-// their results are the same bits; against the reference's layer-by-layer f32 evaluation the difference is the
-// reference's own rounding (F's entries are within half an ulp of the exact composition).
+// Arithmetic: one partial sum per pair of channels — an fmaf chain in f32 over that pair's non-zeros in the observation's
+// scan order — and the partial sums of the non-empty pairs added in f64 in channel order, one rounding to f32 at the
+// end.  List form and dense form follow the same order, so their results are the same bits; against the reference's
+// layer-by-layer f32 evaluation the difference is of the size of the reference's own rounding (F's entries are within
+// half an ulp of the exact composition, a partial sum has ~20 terms where a convolution output has 288 to 1440).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int FD_ROWS = 32 * 32 * 32;  // rows of F: x (5 bits), y (5 bits), channel (5 bits); x, y = 31 unused
 constexpr int FD_G = OBS_C / 2;        // partial sums: one per pair of channels
@@ -928,7 +928,8 @@ __global__ __launch_bounds__(256) void k_fold_out(const double *T0, float *F) {
 
 // list form: one wavefront per agent walks the agent's list, 64 entries per fetch (one per lane, the next 64 requested
 // before these are used); lane l < 40 owns features 4 l .. 4 l + 3 (one 16-byte piece of a row of F), an entry's row and
-// value reach all lanes by v_readlane, eight rows are requested before the first is used.
+// value reach all lanes by v_readlane, eight rows are requested before the first is used.  Lanes past the list's end
+// carry value 0 and row 0 (fmaf(0, w, c) == c: c starts at +0 and so is never -0), so a batch needs no end test.
 __global__ __launch_bounds__(64) void k_feat_list(const float *__restrict__ F, float *__restrict__ feat, int agents, C0List li) {
   const int b = (int)blockIdx.x, l = (int)threadIdx.x;
   if (b >= agents) return;
@@ -940,8 +941,9 @@ __global__ __launch_bounds__(64) void k_feat_list(const float *__restrict__ F, f
   const uint32_t *__restrict__ keys = li.keys + (size_t)b * li.cap;
   const float *__restrict__ vals = li.vals + (size_t)b * li.cap;
   const float *Fl = F + 4 * (l < HID / 4 ? l : 0);
-  double tot[4] = {0.0, 0.0, 0.0, 0.0}, cur[4] = {0.0, 0.0, 0.0, 0.0};
-  uint32_t g = 0u;
+  double tot[4] = {0.0, 0.0, 0.0, 0.0};
+  float cur[4] = {0.f, 0.f, 0.f, 0.f};
+  uint32_t g = 0u;  // the pair of channels of the last entry seen
   uint32_t nkey = (uint32_t)l < n ? keys[l] : 0u;
   float nval = (uint32_t)l < n ? vals[l] : 0.f;
   for (uint32_t e0 = 0u; e0 < n; e0 += 64u) {
@@ -954,35 +956,36 @@ __global__ __launch_bounds__(64) void k_feat_list(const float *__restrict__ F, f
     const uint32_t ch = ((key & 511u) * 57u) >> 9;  // the key's low field is 9 * channel
     const uint32_t rowo = ((((key >> 9) & 1023u) << 5) | ch) * (uint32_t)HID;
     const uint32_t cnt = n - e0 < 64u ? n - e0 : 64u;
+    // which entries open a new pair of channels (the partial sum is closed in front of them)
+    const uint32_t gl = ch >> 1;
+    uint32_t gprev = (uint32_t)__shfl_up((int)gl, 1, 64);
+    if (l == 0) gprev = g;
+    const uint64_t opens = __builtin_amdgcn_ballot_w64((uint32_t)l < cnt && gl != gprev);
+    g = (uint32_t)__builtin_amdgcn_readlane((int)gl, (int)(cnt - 1u));
     constexpr uint32_t U = 8u;
     for (uint32_t u0 = 0u; u0 < cnt; u0 += U) {
       f32x4 w4[U];
 #pragma unroll
-      for (uint32_t u = 0u; u < U; ++u) {
-        const uint32_t s = u0 + u < cnt ? u0 + u : cnt - 1u;
-        w4[u] = ldg4(Fl + (uint32_t)__builtin_amdgcn_readlane((int)rowo, (int)s));
-      }
+      for (uint32_t u = 0u; u < U; ++u) w4[u] = ldg4(Fl + (uint32_t)__builtin_amdgcn_readlane((int)rowo, (int)(u0 + u)));
 #pragma unroll
       for (uint32_t u = 0u; u < U; ++u) {
-        if (u0 + u >= cnt) break;
-        const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)ch, (int)(u0 + u)) >> 1;
-        if (gg != g) {  // the next pair of channels: close the partial sum
-          asm volatile("" ::: "memory");  // (a real branch, taken <= 16 times per agent: not sixteen selects per entry)
-          g = gg;
+        if ((opens >> (u0 + u)) & 1ull) {
+          asm volatile("" ::: "memory");  // (a real branch, taken <= 16 times per agent: not selects on every entry)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) tot[j] += cur[j], cur[j] = 0.0;
+          for (int j = 0; j < 4; ++j) tot[j] += (double)cur[j], cur[j] = 0.f;
         }
-        const double v = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), (int)(u0 + u)));
-        cur[0] = fma(v, (double)w4[u].x, cur[0]);
-        cur[1] = fma(v, (double)w4[u].y, cur[1]);
-        cur[2] = fma(v, (double)w4[u].z, cur[2]);
-        cur[3] = fma(v, (double)w4[u].w, cur[3]);
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), (int)(u0 + u)));
+        cur[0] = fmaf(v, w4[u].x, cur[0]);
+        cur[1] = fmaf(v, w4[u].y, cur[1]);
+        cur[2] = fmaf(v, w4[u].z, cur[2]);
+        cur[3] = fmaf(v, w4[u].w, cur[3]);
       }
     }
   }
   if (l < HID / 4) {
     f32x4 o;
-    o.x = (float)(tot[0] + cur[0]), o.y = (float)(tot[1] + cur[1]), o.z = (float)(tot[2] + cur[2]), o.w = (float)(tot[3] + cur[3]);
+    o.x = (float)(tot[0] + (double)cur[0]), o.y = (float)(tot[1] + (double)cur[1]);
+    o.z = (float)(tot[2] + (double)cur[2]), o.w = (float)(tot[3] + (double)cur[3]);
     *reinterpret_cast<f32x4 *>(feat + (size_t)b * HID + 4 * l) = o;
   }
 }
@@ -993,7 +996,7 @@ __global__ __launch_bounds__(64) void k_feat_list(const float *__restrict__ F, f
 constexpr int FD_T = 64 * FD_G;
 __global__ __launch_bounds__(FD_T) void k_feat_dense(const float *__restrict__ obs, const float *__restrict__ F, float *__restrict__ feat,
                                                      int agents, C0List li) {
-  __shared__ double part[FD_G][HID];
+  __shared__ float part[FD_G][HID];
   __shared__ uint32_t some[FD_G];
   const int t = (int)threadIdx.x, w = t >> 6, l = t & 63;
   auto nxt = [&](int b) {
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(FD_T) void k_feat_dense(const float *__restrict__ o
       const int i = k * 64 + l;
       pre[k] = i < FD_SEG ? __builtin_nontemporal_load(src + i) : 0.f;
     }
-    double cur[4] = {0.0, 0.0, 0.0, 0.0};
+    float cur[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t any = 0u;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -1021,11 +1024,10 @@ __global__ __launch_bounds__(FD_T) void k_feat_dense(const float *__restrict__ o
       const uint32_t idx = (uint32_t)(w * FD_SEG + k * 64 + l);  // = channel * 961 + y * 31 + x
       const uint32_t chn = idx / (uint32_t)(OBS_W * OBS_W), r = idx - chn * (uint32_t)(OBS_W * OBS_W);
       const uint32_t y = r / (uint32_t)OBS_W, x = r - y * (uint32_t)OBS_W;
-      const uint32_t row = (x << 10) | (y << 5) | chn;
+      const uint32_t rowo = ((x << 10) | (y << 5) | chn) * (uint32_t)HID;
       while (m) {  // four non-zeros at a time: their rows of F first, then the sums in scan order
         f32x4 w4[4];
         float vv[4];
-        int nt = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           w4[q] = f32x4{0.f, 0.f, 0.f, 0.f}, vv[q] = 0.f;
@@ -1033,32 +1035,25 @@ __global__ __launch_bounds__(FD_T) void k_feat_dense(const float *__restrict__ o
             const int s = __builtin_ctzll(m);
             m &= m - 1ull;
             vv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre[k]), s));
-            const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)row, s);
-            w4[q] = ldg4(Fl + (size_t)rw * HID);
-            nt = q + 1;
+            w4[q] = ldg4(Fl + (uint32_t)__builtin_amdgcn_readlane((int)rowo, s));
           }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (q < nt) {
-            const double v = (double)vv[q];
-            cur[0] = fma(v, (double)w4[q].x, cur[0]);
-            cur[1] = fma(v, (double)w4[q].y, cur[1]);
-            cur[2] = fma(v, (double)w4[q].z, cur[2]);
-            cur[3] = fma(v, (double)w4[q].w, cur[3]);
-          }
+        for (int q = 0; q < 4; ++q) {  // (an unused slot: value 0 on a zero row, which leaves the sums as they are)
+          cur[0] = fmaf(vv[q], w4[q].x, cur[0]);
+          cur[1] = fmaf(vv[q], w4[q].y, cur[1]);
+          cur[2] = fmaf(vv[q], w4[q].z, cur[2]);
+          cur[3] = fmaf(vv[q], w4[q].w, cur[3]);
+        }
       }
     }
-    if (l < HID / 4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) part[w][4 * l + j] = cur[j];
-    }
+    if (l < HID / 4) *reinterpret_cast<f32x4 *>(&part[w][4 * l]) = f32x4{cur[0], cur[1], cur[2], cur[3]};
     if (l == 0) some[w] = any;
     __syncthreads();
     if (t < HID) {
       double tot = 0.0;
       for (int g = 0; g < FD_G; ++g)
-        if (some[g]) tot += part[g][t];
+        if (some[g]) tot += (double)part[g][t];
       feat[(size_t)b * HID + t] = (float)tot;
     }
     __syncthreads();
