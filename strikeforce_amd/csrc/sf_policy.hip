@@ -942,10 +942,15 @@ __global__ __launch_bounds__(64) void k_feat_list(const float *__restrict__ F, f
   const float *__restrict__ vals = li.vals + (size_t)b * li.cap;
   const float *Fl = F + 4 * (l < HID / 4 ? l : 0);
   double tot[4] = {0.0, 0.0, 0.0, 0.0};
-  float cur[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};  // the open partial sum (v_pk_fma_f32: two features per instruction)
   uint32_t g = 0u;  // the pair of channels of the last entry seen
   uint32_t nkey = (uint32_t)l < n ? keys[l] : 0u;
   float nval = (uint32_t)l < n ? vals[l] : 0.f;
+  auto close = [&]() {
+    asm volatile("" ::: "memory");  // (a real branch, taken <= 16 times per agent: not selects on every entry)
+    tot[0] += (double)c01.x, tot[1] += (double)c01.y, tot[2] += (double)c23.x, tot[3] += (double)c23.y;
+    c01 = f32x2{0.f, 0.f}, c23 = f32x2{0.f, 0.f};
+  };
   for (uint32_t e0 = 0u; e0 < n; e0 += 64u) {
     const uint32_t key = nkey;
     const float val = nval;
@@ -967,25 +972,31 @@ __global__ __launch_bounds__(64) void k_feat_list(const float *__restrict__ F, f
       f32x4 w4[U];
 #pragma unroll
       for (uint32_t u = 0u; u < U; ++u) w4[u] = ldg4(Fl + (uint32_t)__builtin_amdgcn_readlane((int)rowo, (int)(u0 + u)));
+      const uint32_t ob = (uint32_t)(opens >> u0) & 0xffu;
+      if (ob == 0u) {  // the usual batch: all eight entries go on with the open partial sum
 #pragma unroll
-      for (uint32_t u = 0u; u < U; ++u) {
-        if ((opens >> (u0 + u)) & 1ull) {
-          asm volatile("" ::: "memory");  // (a real branch, taken <= 16 times per agent: not selects on every entry)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) tot[j] += (double)cur[j], cur[j] = 0.f;
+        for (uint32_t u = 0u; u < U; ++u) {
+          const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), (int)(u0 + u)));
+          const f32x2 vv = {v, v};
+          c01 = __builtin_elementwise_fma(vv, f32x2{w4[u].x, w4[u].y}, c01);
+          c23 = __builtin_elementwise_fma(vv, f32x2{w4[u].z, w4[u].w}, c23);
         }
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), (int)(u0 + u)));
-        cur[0] = fmaf(v, w4[u].x, cur[0]);
-        cur[1] = fmaf(v, w4[u].y, cur[1]);
-        cur[2] = fmaf(v, w4[u].z, cur[2]);
-        cur[3] = fmaf(v, w4[u].w, cur[3]);
+      } else {
+#pragma unroll
+        for (uint32_t u = 0u; u < U; ++u) {
+          if ((ob >> u) & 1u) close();
+          const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), (int)(u0 + u)));
+          const f32x2 vv = {v, v};
+          c01 = __builtin_elementwise_fma(vv, f32x2{w4[u].x, w4[u].y}, c01);
+          c23 = __builtin_elementwise_fma(vv, f32x2{w4[u].z, w4[u].w}, c23);
+        }
       }
     }
   }
   if (l < HID / 4) {
     f32x4 o;
-    o.x = (float)(tot[0] + (double)cur[0]), o.y = (float)(tot[1] + (double)cur[1]);
-    o.z = (float)(tot[2] + (double)cur[2]), o.w = (float)(tot[3] + (double)cur[3]);
+    o.x = (float)(tot[0] + (double)c01.x), o.y = (float)(tot[1] + (double)c01.y);
+    o.z = (float)(tot[2] + (double)c23.x), o.w = (float)(tot[3] + (double)c23.y);
     *reinterpret_cast<f32x4 *>(feat + (size_t)b * HID + 4 * l) = o;
   }
 }
