@@ -4,11 +4,21 @@
  * (StrikeForce-client/bots/bot-0.5/Agent.hpp:178-214 predict(), Modules.hpp:54-179 AgentModel).  This
  * library evaluates the same network for every agent of an arena batch in one pass on the GPU, reading
  * the observation buffer sf_observe_device() wrote and producing the command chars sf_step_device()
- * consumes, so the 123 KB/agent observation never leaves HBM.  Inputs, outputs, state and accumulation are f32;
- * the matrix products run on the f32-input MFMA or — conv1 and conv2 at 16 384 rows and more — on the bf16
- * MFMA with every f32 operand split into three bf16 parts, which keeps the error at the level of one f32
- * rounding per product (|err| <= 2e-6 * sum|a*w| either way; SF_POLICY_F32_CONV=1 in the environment at
- * sf_policy_create keeps everything on the f32 pipe).  Every agent keeps its own recurrent state exactly as one
+ * consumes, so the 123 KB/agent observation never leaves HBM.  Inputs, outputs and state are f32.
+ *
+ * The convolution stack.  GameCNN::forward (Modules.hpp:66-71) applies four bias-free 3x3 / stride-2 convolutions with
+ * nothing between them: one linear map of the 32 x 31 x 31 observation onto 160 features.  sf_policy_create composes the
+ * four weight tensors into that map's matrix once (f64 on the device, rounded to f32), and a forward pass adds up one
+ * row of it per non-zero float of the observation (about 1 % of the floats are non-zero): f32 fmaf chains per pair of
+ * channels, combined in f64.  Same function as the layer-by-layer evaluation, 0.1 instead of 48.6 MFLOP per agent; the
+ * difference from the reference's f32 layer-by-layer result is of the size of that result's own rounding (tests: |err| <=
+ * 1e-6 + 5e-5 |ref| on probabilities, value and recurrent state against the reference's own AgentModel).
+ * SF_POLICY_LAYERED=1 in the environment at sf_policy_create evaluates the four layers one after the other instead
+ * (conv0 on the non-zeros; conv1 and conv2 — at 16 384 rows and more — on the bf16 MFMA with every f32 operand split
+ * into three bf16 parts, |err| <= 2e-6 * sum|a*w|; conv3 on the f32 MFMA; SF_POLICY_F32_CONV=1 keeps all of them on the
+ * f32 pipe): the cross-check path, held to the same tests.
+ * Everything behind the convolutions (two GRU cells, combined_processor, the ResB heads) runs on the f32-input MFMA
+ * (bit for bit an fmaf chain).  Every agent keeps its own recurrent state exactly as one
  * reference `Agent` object does.  Inference only: the PPO learner (Agent.hpp:270-420) is out of scope.
  *
  * Same conventions as strikeforce.h: plain pointers and sizes, 0 = success, sf_last_error() for text,
@@ -71,7 +81,7 @@ int sf_policy_reset_memory_n(sf_policy *p, const uint8_t *d_mask, int32_t agents
 int sf_policy_forward(sf_policy *p, const float *d_obs, int32_t agents, float *d_probs, float *d_value);
 
 /* sf_policy_forward on the observation in list form (sf_observe_sparse_device: d_keys / d_vals [agents][cap],
- * d_counts [agents], d_pov [agents][160]): the first convolution takes the non-zeros as they come instead of scanning a
+ * d_counts [agents], d_pov [agents][160]): the convolution stack takes the non-zeros as they come instead of scanning a
  * dense 123 KB buffer per agent for them, and the five centre cells come from d_pov.  Same results as the dense call,
  * bit for bit (same values applied in the same order).  An agent whose count exceeds cap or 2048, or is the
  * 0xffffffff marker, is evaluated on an empty observation and counted: sf_policy_sparse_overflows() returns (and
@@ -80,7 +90,7 @@ int sf_policy_forward_sparse(sf_policy *p, const uint32_t *d_keys, const float *
                              const float *d_pov, int32_t cap, int32_t agents, float *d_probs, float *d_value);
 /* The same with a dense fallback, so that no agent is ever evaluated on a blank window: the agents whose list did not
  * fit are redone from their rows of d_dense (what sf_observe_overflow_device wrote: [agents][32][31][31]; the other rows
- * are never read) by a second conv0 launch that is idle when every list fitted.  Results equal the dense pair of calls
+ * are never read) by a second launch that is idle when every list fitted.  Results equal the dense pair of calls
  * bit for bit for every agent; nothing is counted in sf_policy_sparse_overflows. */
 int sf_policy_forward_sparse_or_dense(sf_policy *p, const uint32_t *d_keys, const float *d_vals, const uint32_t *d_counts,
                                       const float *d_pov, int32_t cap, int32_t agents, const float *d_dense,
@@ -111,9 +121,10 @@ int sf_policy_kernel_time(sf_policy *p, int32_t enable, float *ms, double *flop,
  * kernel (k_gemm_b3: conv1 / conv2 at M >= 16 384).  flop[] is the algorithmic 2*M*N*K in both; the split kernel
  * executes six bf16 products per algorithmic one. */
 int sf_policy_kernel_time_ex(sf_policy *p, int32_t enable, float ms[2], double flop[2], int32_t launches[2]);
-/* The same by kernel: 0 k_gemm (f32 MFMA) + fix-ups, 1 k_gemm_b3 (conv1 / conv2 on the bf16 pipe), 2 conv0 on the
- * non-zeros (list form; flop[2] = 0: the useful work depends on the lists, 2 * 160 * sum over non-zeros of the output
- * pixels they reach), 3 k_tail (conv3 + GRU cells + combined_processor + heads). */
+/* The same by kernel: 0 k_gemm (f32 MFMA) + fix-ups, 1 k_gemm_b3 (conv1 / conv2 on the bf16 pipe; layered form only),
+ * 2 the launch that takes the observation's non-zeros — k_feat_list, the composed convolution stack (layered form:
+ * k_conv0_sparse); flop[2] = 0: the useful work depends on the lists, 2 * 160 per non-zero — 3 k_tail (GRU cells +
+ * combined_processor + heads; conv3 too in the layered form). */
 int sf_policy_kernel_time_by_kernel(sf_policy *p, int32_t enable, float ms[4], double flop[4], int32_t launches[4]);
 
 /* The matrix kernel on its own, for unit tests and roofline measurements: C[M][ldc] = A[M][lda] * W[N][K]^T + bias
