@@ -114,6 +114,10 @@ DIMS_LINE = ("gameplay.hpp", 37)
 
 NATIVE_DIMS = (3, 30, 100, 9000, 9000, 9000, 9000)
 BENCH_DIMS = (1, 64, 64, 8, 24, 64, 9000)  # BASELINE.json configs[2]: 64x64, H8 Z24 B64 (bench.py cpu_baseline, kind "reference")
+# the other dimension sets tests/ref_cases.py plays (configs[0], configs[1], STRESS, the Squad and three-floor cases): the
+# default call compiles them too, side by side, so that the first test run does not compile them one after the other
+TEST_DIMS = [(1, 32, 32, 1, 4, 16, 9000), (1, 64, 64, 1, 16, 32, 9000), (1, 24, 40, 6, 12, 5, 6),
+             (1, 28, 36, 12, 10, 48, 9000), (3, 20, 30, 12, 10, 32, 9000)]
 
 
 def binary_for(dims=None, squad_agents=False):
@@ -196,7 +200,10 @@ if __name__ == "__main__":
         print(manifest())
     else:
         build(a.ref, a.quiet, [int(x) for x in a.dims.split(",")] if a.dims else None, a.squad_agents)
-        if not a.dims and not a.squad_agents:  # the default call (oracle/Makefile `ref`) also makes the Squad-agents flavour
-            build(a.ref, a.quiet, None, True)
-            build(a.ref, a.quiet, BENCH_DIMS)  # and the one bench.py times as its cpu_baseline (BASELINE configs[2])
+        if not a.dims and not a.squad_agents:  # the default call (oracle/Makefile `ref`) also makes the Squad-agents flavour,
+            # the one bench.py times as its cpu_baseline (BASELINE configs[2]) and the tests' dimension sets
+            from concurrent.futures import ThreadPoolExecutor
+            jobs = [(None, True), (BENCH_DIMS, False)] + [(d, False) for d in TEST_DIMS]
+            with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+                list(ex.map(lambda j: build(a.ref, a.quiet, j[0], j[1]), jobs))
     sys.exit(0)
