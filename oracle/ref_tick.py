@@ -114,10 +114,11 @@ DIMS_LINE = ("gameplay.hpp", 37)
 
 NATIVE_DIMS = (3, 30, 100, 9000, 9000, 9000, 9000)
 BENCH_DIMS = (1, 64, 64, 8, 24, 64, 9000)  # BASELINE.json configs[2]: 64x64, H8 Z24 B64 (bench.py cpu_baseline, kind "reference")
-# the other dimension sets tests/ref_cases.py plays (configs[0], configs[1], STRESS, the Squad and three-floor cases): the
+# the other dimension sets the tests play (configs[0], configs[1], STRESS, the Squad and three-floor cases, the one-slot
+# bullet pool of tests/test_order_scenarios.py): the
 # default call compiles them too, side by side, so that the first test run does not compile them one after the other
 TEST_DIMS = [(1, 32, 32, 1, 4, 16, 9000), (1, 64, 64, 1, 16, 32, 9000), (1, 24, 40, 6, 12, 5, 6),
-             (1, 28, 36, 12, 10, 48, 9000), (3, 20, 30, 12, 10, 32, 9000)]
+             (1, 28, 36, 12, 10, 48, 9000), (3, 20, 30, 12, 10, 32, 9000), (3, 30, 100, 12, 4, 1, 4)]
 
 
 def binary_for(dims=None, squad_agents=False):

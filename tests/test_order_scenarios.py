@@ -70,9 +70,9 @@ class Sim:
 class RefSim:
     """The reference itself (Squad: built with USE_AGENT_IN_SQUAD_NPCS, keyboard player + scripted agents)."""
 
-    def __init__(self, w, tb, player, squad):
+    def __init__(self, w, tb, player, squad, native_caps=True):
         self.like = Oracle(w)  # only for the dump fields the reference has no counterpart of (reftick.RefTick.dump)
-        self.r = reftick.RefTick(w, player, agents=False, squad_agents=squad)
+        self.r = reftick.RefTick(w, player, agents=False, squad_agents=squad, native_caps=native_caps)
         self.r.reset(tb, SERIAL)
         self.w = w
 
@@ -139,8 +139,8 @@ def close(s):
         s.r.close()
 
 
-def make(impl, w, tb, player=P300, squad=False):
-    return RefSim(w, tb, player, squad) if impl == "reference" else Sim(impl, w, tb)
+def make(impl, w, tb, player=P300, squad=False, native_caps=True):
+    return RefSim(w, tb, player, squad, native_caps) if impl == "reference" else Sim(impl, w, tb)
 
 
 def quiet(d, humans):
@@ -293,6 +293,41 @@ def test_bullets_on_a_built_entrance_are_absorbed_until_it_breaks(impl):
     assert d.portals[0].active == 0 and quiet(d, 1) and draws_ok(d, 8)
     d = s.step("x")  # the cell is plain floor now: the shot flies (1,2) -> (1,3) is wall: it dies in the first update_bull
     assert sum(b.alive for b in d.bullets) == 0 and d.dmg[UP] == 0
+
+
+# ---- a covered exit radiates only while a bullet slot is free (App. E-9) ------------------------------------------------------------
+@pytest.mark.parametrize("impl", IMPLS_REF)
+def test_a_covered_exit_radiates_only_while_the_bullet_pool_has_a_free_slot(impl):
+    """Solo, a bullet pool of ONE slot (B = 1; the reference compiled with that pool).  The player builds the exit 'O' on
+    (2,1) and the entrance '^' on (1,2) as above, takes the AK_47 in hand and steps onto its own entrance: teleport() puts
+    it on the exit (gameplay.hpp:517-530), facing right (a move does not turn).  An exit that no longer shows 'O' radiates:
+    portal_damage() puts a bullet of damage 20, effect -10, range 1 on it (gameplay.hpp:1279-1297), hit_human of the same
+    half-tick gives it to the man standing there and frees the slot (:611-634): Hp -20, mindamage -10 per step.
+    Then the player fires along the corridor (2,2)..(2,7): the shot takes the pool's only slot in human_action (after
+    that step's radiation), moves one cell per update_bull — two per step — and dies at the wall (2,8) in the first
+    update_bull of the third step after the shot (it is put on column 2 and needs columns 3..7: five moves, the sixth
+    meets the wall; gameplay.hpp:1080-1093).  portal_damage runs BEFORE that update_bull, so for three steps
+    `index = b_ind()` is -1 and the function returns without radiating (:1287-1289): the Hp stands still, then falls again."""
+    w = world([(0, 1, 1), (0, 2, 1), (0, 1, 2)] + [(0, 2, c) for c in range(2, 8)], abi.MODE_SOLO, 1,
+              player=config.HUMAN_ENEMY_TOKENS, B=1)
+    s = make(impl, w, 1700000000, player=config.HUMAN_ENEMY_TOKENS, native_caps=False)
+    for ch in "]q]md":
+        d = s.step(ch)
+    h = d.humans[0]
+    assert (h.r, h.c, h.way, h.vec, h.ind, h.hp, h.mindamage) == (2, 1, 2, 2, 4, 1000, 100) and quiet(d, 1)
+    d = s.step("+")                                   # step 6: the first radiation
+    assert (d.humans[0].hp, d.humans[0].mindamage) == (980, 90) and sum(b.alive for b in d.bullets) == 0
+    d = s.step("x")                                   # step 7: radiation, then the shot: on (2,2), moved to (2,3)
+    assert (d.humans[0].hp, d.humans[0].mindamage, d.humans[0].stamina) == (960, 80, 1000000 - 50)
+    assert [(b.r, b.c, b.way) for b in d.bullets if b.alive] == [(2, 3, 2)]
+    for n, col in ((8, 5), (9, 7), (10, None)):      # the pool is dry when portal_damage looks: no radiation
+        d = s.step("+")
+        assert (d.humans[0].hp, d.humans[0].mindamage) == (960, 80), n
+        assert [(b.r, b.c) for b in d.bullets if b.alive] == ([(2, col)] if col else []), n
+    d = s.step("+")                                   # step 11: the slot is free again
+    assert (d.humans[0].hp, d.humans[0].mindamage) == (940, 70)
+    assert quiet(d, 1) and draws_ok(d, 11)
+    close(s)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
