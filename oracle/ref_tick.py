@@ -10,20 +10,24 @@ the six files below into a temporary directory with the line ranges listed in OM
 so that line numbers in the copy are the reference's own), and compiles oracle/ref_tick_main.cpp (ours) against the
 copies.  Every kept line is the reference's, unedited; no stand-in is written for any omitted header, function or
 object — what is omitted is simply not there, and nothing kept calls it (the compiler checks that).  Every omitted range
-is a whole declaration or member function and carries its reason below; anchor texts on the first and last line of
-each range make a reference whose lines have moved fail loudly.  The temporary directory is deleted; the binary lands
+is a whole declaration or member function — or, inside check_end only, a whole statement that draws the end screen or
+waits for the space key — and carries its reason below; anchor texts on the first and last line of each range make a
+reference whose lines have moved fail loudly.  The temporary directory is deleted; the binary lands
 in oracle/_ref/ (git-ignored).  Without a checkout nothing is built (exit code 0).
 
 The one class the reference leaves to the user is `Agent` (random.hpp:25 -> selected_agent.hpp:25 picks a bot's
 Agent.hpp; bots/bot-0/Agent.hpp:27-37 is the minimal form): ref_tick_main.cpp supplies a scripted one, which is the
 plug-in contract, not a stand-in.  What ref_tick_main.cpp restates from the omitted play() is the ORDER of its calls
 (gameplay.hpp:1441-1471, fifteen lines) and get_my_action's two lines that fetch the player's command
-(gameplay.hpp:955-960, incl. client.send_it() in an online match); check_end (gameplay.hpp:1102-1229: screens and key
-waits around five comparisons) stays out, so SURVEY §8 row a19 remains pinned by hand-derived scenarios only.
+(gameplay.hpp:955-960, incl. client.send_it() in an online match).  check_end (gameplay.hpp:1102-1229) is kept: its
+comparisons, its bookkeeping and its return value; of its lines only `render_it();`, `if(printThread.joinable())
+printThread.join();`, `printer.print(...)` and `while(getch() != ' ');` are blanked (eleven groups, OMIT below), so SURVEY
+§8 row a19 is pinned on the reference's own function (tests/test_ref_check_end.py; its Timer branch reads time(0) and is
+not comparable under a fixed tb).
 
-Pins (tests/test_ref_tick.py): rows a4-a18 and a20 — Backpack/Human, gen_human, node/showit, the slot allocators, the
+Pins (tests/test_ref_tick.py): rows a4-a20 — Backpack/Human, gen_human, node/showit, the slot allocators, the
 three spawns, zombie_action, portal_damage, update_tmp, hit_human/hit_zombie, update_bull, human_action / get_command /
-human_rnpc_bot, obey, teleport, claim_chest, setup/load_data (Solo, Timer, Squad), describe + gameplay::bot — on the
+human_rnpc_bot, obey, teleport, claim_chest, setup/load_data (Solo, Timer, Squad), check_end, describe + gameplay::bot — on the
 reference's native world (gameplay.hpp:37: 3 floors x 30 x 100, its caps of 9000 never reached).  Also: load_data's
 logging / replay branches (.sf_sample, tests/test_ref_replay.py) and its online branch + class Client, in a real match
 through the reference's own server (tests/test_lockstep_server.py).
@@ -70,7 +74,21 @@ OMIT = {
         (823, 927, "void my_command(){", "}", "keyboard (kbhit/getch) and command_list()"),
         (939, 963, "void get_my_action(){", "}", "my_command(), render_it(), printer"),
         (1014, 1057, "void command_list(bool b = false){", "}", "printer"),
-        (1102, 1229, "bool check_end(){", "}", "printer, render_it(), getch around the end conditions"),
+        # check_end (gameplay.hpp:1102-1229) stays — its comparisons, its bookkeeping (money, level-ups, the online
+        # player's last send) and its return value are what play() acts on (`if(check_end()) break;` :1450) — without
+        # the statements that draw the end screen and wait for the space key: whole statements on their own lines,
+        # none of them the sole body of an `if`
+        (1114, 1118, "render_it();", "while(getch() != ' ');", "check_end, match won: end screen + key wait"),
+        (1123, 1126, "render_it();", 'printer.print("You\'re disconnected :(\\npress space button to continue\\n");', "check_end, disconnected: end screen"),
+        (1128, 1128, "while(getch() != ' ');", "while(getch() != ' ');", "check_end, disconnected: key wait"),
+        (1138, 1142, "render_it();", "while(getch() != ' ');", "check_end, player dead: end screen + key wait"),
+        (1149, 1153, "render_it();", "while(getch() != ' ');", "check_end, Timer lost: end screen + key wait"),
+        (1167, 1170, "render_it();", "printer.print(s);", "check_end, Timer won: end screen"),
+        (1176, 1176, "while(getch() != ' ');", "while(getch() != ' ');", "check_end, Timer won: key wait"),
+        (1193, 1196, "render_it();", "printer.print(s);", "check_end, Solo won: end screen"),
+        (1202, 1202, "while(getch() != ' ');", "while(getch() != ' ');", "check_end, Solo won: key wait"),
+        (1216, 1219, "render_it();", "printer.print(s);", "check_end, Squad won: end screen"),
+        (1225, 1225, "while(getch() != ' ');", "while(getch() != ' ');", "check_end, Squad won: key wait"),
         (1420, 1426, "void render_it(){", "}", "starts print_game on a thread"),
         (1428, 1505, "void play(){", "}", "printer.start/stop, get_my_action, check_end, render_it; its call ORDER is restated in ref_tick_main.cpp"),
         (1507, 1678, "void open(){", "}", "menus: head(), usleep, play()"),
@@ -86,6 +104,8 @@ CONTEXT = [
     ("gameplay.hpp", 695, "void obey(const char c, Environment::Character::Human &player){"),
     ("gameplay.hpp", 965, "void human_action(){"),
     ("gameplay.hpp", 1059, "void update_bull(){"),
+    ("gameplay.hpp", 1102, "bool check_end(){"),
+    ("gameplay.hpp", 1229, "}"),
     ("gameplay.hpp", 1231, "void setup(){"),
     ("gameplay.hpp", 1739, "} g;"),
     ("gameplay.hpp", 1741, "void gameplay::load_data(){"),

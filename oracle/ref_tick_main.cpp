@@ -16,9 +16,11 @@
 //                                   match server — load_data asks for IP, port and password on the next three stdin lines
 //                                   (gameplay.hpp:1806-1817) — as the reference client does; `step` sends the player's command
 //                                   (client.send_it, gameplay.hpp:959-960) and human_action receives the others' (:977-978)
-//   reset <tb> <serial>             setup(); _srand(tb, serial); ++frame; loop-top spawns
+//   reset <tb> <serial>             setup(); _srand(tb, serial); ++frame; loop-top spawns and end check
 //   step <chars>                    one iteration of play()'s loop + the next loop top; chars[0] = the player's command,
-//                                   chars[k] = the scripted action of human k's agent (where it has one)
+//                                   chars[k] = the scripted action of human k's agent (where it has one); answers the six
+//                                   draw counts and what check_end() returned at that loop top (`if(check_end()) break;`
+//                                   gameplay.hpp:1450 — its screens and key waits are blanked, oracle/ref_tick.py)
 //   dump <H> <Z> <B> <P>            state of the first H/Z/B/P slots and of every cell, in sf_*_rec word order
 //   calls                           predict/update calls since the last `calls`
 //   obs <agent id>                  the observation that agent's last predict() received (30752 hex words)
@@ -29,10 +31,10 @@
 //   reset_native                    setup() with the seeds it makes itself (time(), libc rand: gameplay.hpp:1233,1745-1747)
 //                                   or, in replay mode, reads from the sample; answers "ok <tb> <serial>"
 //   logclose                        closes the log; answers its path (relative to the working directory)
-//   rivals                          gameplay::rivals_are_dead() (gameplay.hpp:497-505), the one helper of check_end that is in the build
+//   rivals                          gameplay::rivals_are_dead() (gameplay.hpp:497-505), check_end's helper
 //   bench <steps> <seed>            timing (bench.py's cpu_baseline): `steps` iterations under the 28-command random agent
 //                                   of SURVEY §8d (LCG x <- 1664525 x + 1013904223, command (x >> 16) % 28); when the
-//                                   player is dead the game is set up again with tb + 1 (check_end is not in the build)
+//                                   player is dead the game is set up again with tb + 1
 //   quit
 #include <chrono>
 #include <cstdint>
@@ -110,6 +112,9 @@ void loop_top() {  // gameplay.hpp:1444-1449
     if (g.frame % g.ph <= 1) g.spawn_human_npc();
 }
 
+int ended = 0;
+void end_check() { ended = g.check_end() ? 1 : 0; }  // gameplay.hpp:1450 (Timer: the reference's clock is time(0), :1145)
+
 long long phase_draws[6];
 
 void half_tick(int k) {  // gameplay.hpp:1457-1463 == 1465-1471 (view / find_recom / render_it draw; `start` is the frame clock)
@@ -151,6 +156,7 @@ void one_step(const std::string &cmds) {
     ++steps;
     loop_top();          // the next iteration's :1444-1449
     phase_draws[4] = j - j0;
+    end_check();         // :1450
 }
 
 // The state in the word order of include/strikeforce.h's dump records (sf_human_rec 28 words with `profile` = -1: the
@@ -265,6 +271,7 @@ int main() {
             steps = 0;
             ++g.frame;   // gameplay.hpp:1441
             loop_top();
+            end_check();
             printf("ok\n");
         } else if (s.rfind("logging ", 0) == 0) {
             g.enable_logging = atoi(s.c_str() + 8) != 0;
@@ -281,6 +288,7 @@ int main() {
             steps = 0;
             ++g.frame;
             loop_top();
+            end_check();
             if (g.online)
                 printf("ok %lld %lld %d %d %d %d\n", client.tb, g.serial_number, ind, client.n, client.team, (int)disconnect);
             else
@@ -292,8 +300,8 @@ int main() {
             printf("ok %s\n", g.log_filename.c_str());
         } else if (s.rfind("step", 0) == 0) {
             one_step(s.size() > 5 ? s.substr(5) : std::string());
-            printf("ok %lld %lld %lld %lld %lld %lld\n", phase_draws[0], phase_draws[1], phase_draws[2], phase_draws[3],
-                   phase_draws[4], phase_draws[5]);
+            printf("ok %lld %lld %lld %lld %lld %lld %d\n", phase_draws[0], phase_draws[1], phase_draws[2], phase_draws[3],
+                   phase_draws[4], phase_draws[5], ended);
         } else if (s.rfind("dump ", 0) == 0) {
             int a, b, c, d;
             sscanf(s.c_str() + 5, "%d %d %d %d", &a, &b, &c, &d);

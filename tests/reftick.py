@@ -164,7 +164,11 @@ class RefTick:
         assert len(r) == 1 and r[0].startswith("ok "), r
         # generator draws of this step by phase: zombie_action, update_bull (1st), human_action, update_bull (2nd),
         # the next loop top's spawns, everything else
-        self.phase_draws = [int(x) for x in r[0].split()[1:]]
+        t = [int(x) for x in r[0].split()[1:]]
+        self.phase_draws = t[:6]
+        # what the reference's own check_end() returned at the loop top behind this step (gameplay.hpp:1450; its Timer
+        # branch reads time(0), gameplay.hpp:1145: not meaningful under a fixed tb)
+        self.ended = bool(t[6])
 
     def calls(self):
         """[(agent id, 'N'ew|'D'eleted|'P'redict|'U'pdate, a, b, frame)] since the last call."""

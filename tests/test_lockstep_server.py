@@ -248,3 +248,88 @@ def test_the_reference_client_and_two_of_ours_play_one_match():
         shadow.step(np.frombuffer(relayed[0][it], dtype=np.uint8))
         d = reftick.first_difference(ref_dumps[it], reftick.arrays_of(shadow.dump(0)))
         assert d is None, "iteration %d: %s" % (it, d)
+
+
+def test_the_reference_client_wins_the_match_when_both_rivals_have_quit():
+    """check_end's online branch on the reference's own client (gameplay.hpp:1103-1119; kept in oracle/_ref/sf_ref_tick
+    with only its end screen and key wait blanked, oracle/ref_tick.py): the two other players — strikeforce_amd.lockstep
+    clients — leave the match with '_' at iterations 5 and 8 ('_' takes the player's Hp to 0 in every simulation,
+    gameplay.hpp:696-699; its client is gone, :939-953).  The reference client's check_end() must say "go on" at every loop
+    top before, and "over" (`online && rivals_are_dead()`) at the loop top behind iteration 8 — where a shadow oracle
+    with the reference client's `ind`, fed the relayed commands, ends too, won."""
+    import reftick
+    if not reftick.available():
+        pytest.skip("oracle/_ref/sf_ref_tick not built")
+    from oracle_lib import Oracle
+    import ctypes as C
+    rich = [15000, 1000, 15000, 10, 10, 10, 300000, 60, 0, 0, 0, 1, 1, 1, 34] + [1] * 16 + [56]
+    teams, quits = [1, 2, 3], {0: 5, 2: 8}
+    port, password = _free_port(), "sesame"
+    proc = _start_server(port, password, teams)
+    m, portal = config.synthetic_map(28, 36, wall_p=0.04, portal_pairs=1)
+    cfg0 = config.make_config(1, 28, 36, H=12, Z=10, B=48, P=48, mode=abi.MODE_BATTLE, n_agents=3, teams=teams, auto_reset=0,
+                              player_tokens=rich)
+    ref = reftick.RefTick(config.Workload("match", cfg0, m, portal), rich, native_caps=False)
+    errors, ours, ref_cmds, ref_ended, ref_info = [], {}, [], [], {}
+
+    def ref_thread():
+        try:
+            tb, serial, ind, n, team = ref.join_match("127.0.0.1", port, password)
+            ref_info.update(tb=tb, serial=serial, ind=ind)
+            rng = np.random.RandomState(78)
+            for it in range(40):
+                c = abi.BENCH_COMMANDS[rng.randint(0, 28)]
+                ref_cmds.append(c)
+                ref.step(c)
+                ref_ended.append(ref.ended)
+                if ref.ended:
+                    break
+        except Exception as e:  # noqa: BLE001
+            errors.append(("reference client", repr(e)))
+
+    def our_thread(k):
+        try:
+            c = lockstep.MatchClient("127.0.0.1", port, password, rich, name="p%d" % k).connect()
+            sim = Oracle(c.workload(28, 36, m, portal, H=12, Z=10, B=48, P=48))
+            ours[c.ind] = c
+            rng = np.random.RandomState(2000 + c.ind)
+            policy = lambda _s, it: "_" if it == quits[c.ind] else abi.BENCH_COMMANDS[rng.randint(0, 28)]
+            how = lockstep.play(c, sim, policy, max_iterations=40)
+            assert how == (quits[c.ind], "quit"), how
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=our_thread, args=(0,)), threading.Thread(target=ref_thread), threading.Thread(target=our_thread, args=(2,))]
+    for t in threads:
+        t.start()
+        time.sleep(0.4)  # connection order = player index
+    for t in threads:
+        t.join(timeout=60)
+    ref.close()
+    try:
+        proc.stdin.write("done!\\n")
+        proc.stdin.flush()
+        proc.wait(timeout=3)
+    except Exception:  # noqa: BLE001
+        proc.kill()
+    assert not errors, errors
+    assert ref_info["ind"] == 1
+    assert ref_ended == [False] * 8 + [True], ref_ended
+    # the shadow: the match as the reference client's process sees it (ind = 1); the others' commands are random until they quit
+    c0 = ours[0]
+    cfg = config.make_config(1, 28, 36, H=12, Z=10, B=48, P=48, mode=abi.MODE_BATTLE, level=1, n_agents=3, teams=c0.teams,
+                             auto_reset=0, player_tokens=rich, ind=1, agent_tokens=c0.records)
+    shadow = Oracle(config.Workload("shadow", cfg, m, portal))
+    shadow.reset((C.c_uint64 * 1)(c0.tb), (C.c_uint64 * 1)(c0.serial))
+    rngs = {k: np.random.RandomState(2000 + k) for k in (0, 2)}
+    for it in range(9):
+        cmd = [ord("+")] * 3
+        cmd[1] = ord(ref_cmds[it])
+        for k in (0, 2):
+            if it < quits[k]:
+                cmd[k] = ord(abi.BENCH_COMMANDS[rngs[k].randint(0, 28)])
+            elif it == quits[k]:
+                cmd[k] = ord("_")
+        shadow.step(np.array(cmd, dtype=np.uint8))
+        assert bool(shadow.done()[0]) == ref_ended[it], "iteration %d" % it
+    assert shadow.dump(0).hdr.outcome == abi.WON

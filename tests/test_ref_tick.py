@@ -7,9 +7,10 @@ character records, levels 1-4.  After EVERY step the whole state is compared: ev
 and exit slot, every cell's bits, damage and exit number, the counters, the generator's 18 registers and its draw count
 — and the number of draws each phase of the step made (zombie_action, the two update_bull, human_action, the spawns).
 
-This pins SURVEY §8 rows a4-a18 and a20 on the reference itself (a1-a3: tests/test_ref_slices.py).  Not in the build,
-hence not pinned here: check_end (a19; it is screens and key waits around its comparisons) and the online branch of
-load_data.  Skipped where the binary was never built (no reference checkout)."""
+This pins SURVEY §8 rows a4-a20 on the reference itself (a1-a3: tests/test_ref_slices.py).  check_end (a19) is in the
+build with only its end screens and key waits blanked: what it returns at every loop top is compared here, whole games
+to their end in tests/test_ref_check_end.py.  The online branch of load_data: tests/test_lockstep_server.py.
+Skipped where the binary was never built (no reference checkout)."""
 import os
 
 import numpy as np
@@ -27,9 +28,9 @@ EVENTS = {}
 
 
 def lockstep(w, player, tb, serial, steps, cmd_seed, observe_every=0, min_steps=1, native_caps=True):
-    """Reference and oracle side by side; returns the number of steps compared (the run stops when the oracle's
-    end check fires — check_end is not in the reference build — or when the reference's population outgrows the
-    configuration's slot pools, 64 / 64 / 256 against its own 9000)."""
+    """Reference and oracle side by side; returns the number of steps compared (the run stops when the game ends —
+    the reference's own check_end() and the oracle's are compared at every loop top — or when the reference's
+    population outgrows the configuration's slot pools, 64 / 64 / 256 against its own 9000)."""
     o = Oracle(w)
     r = reftick.RefTick(w, player, native_caps=native_caps)
     try:
@@ -57,6 +58,10 @@ def lockstep(w, player, tb, serial, steps, cmd_seed, observe_every=0, min_steps=
             d = reftick.first_difference(rd, reftick.arrays_of(od))
             assert d is None, "step %d (command %r): %s" % (s, chr(cmds[s, 0, 0]), d)
             done = s + 1
+            # row a19: the reference's own check_end() at this loop top (gameplay.hpp:1102-1229, 1450) against ours.  (Timer:
+            # the reference's clock is time(0) - tb, ours the frame count: DESIGN §8.)
+            if w.cfg.mode != abi.MODE_TIMER:
+                assert r.ended == bool(od.hdr.done), "step %d: check_end() says %s, ours %s" % (s, r.ended, od.hdr.done)
             if od.hdr.done:
                 break
         for k, v in o.events().items():
@@ -128,7 +133,7 @@ def test_squad_on_a_small_three_floor_world():
 
 def test_every_tick_branch_was_met_in_the_pinned_runs():
     """The oracle's branch counters summed over the runs above: the comparison saw every kind of event the tick path
-    has (`episode_end` belongs to check_end, which is not in the reference build)."""
+    has (`episode_end`: tests/test_ref_check_end.py plays games to their end)."""
     if len(EVENTS) == 0:
         pytest.skip("runs after the lock-step tests of this module")
     missing = [k for k, v in EVENTS.items() if v == 0 and k != "episode_end"]

@@ -118,11 +118,12 @@ def test_squad_agents_observe_and_die_as_in_the_reference(impl):
         d = reftick.first_difference(r.dump(), reftick.arrays_of(sim.dump(0) if impl is not Device else _gpu_dump(sim)))
         assert d is None, "step %d: %s" % (s, d)
         assert list(sim.agent_alive()[0]) == r.active_agents[:10], "step %d" % s
-        # check_end's helper rivals_are_dead() (gameplay.hpp:497-505; check_end itself is not in the reference build):
+        # check_end's helper rivals_are_dead() (gameplay.hpp:497-505), and check_end itself (the Squad game goes on):
         # no living human of a team other than 0 and the player's
         dd = sim.dump(0) if impl is not Device else _gpu_dump(sim)
         mine = dd.humans[0].team
         assert r.rivals_are_dead() == (not any(h.alive and h.team not in (0, mine) for h in dd.humans)), "step %d" % s
+        assert r.ended == bool(sim.done()[0]), "step %d: the reference's check_end() says %s" % (s, r.ended)
         deaths += sum(1 for c in calls if c[1] == "D")
         if sim.done()[0]:
             break
