@@ -34,8 +34,10 @@ for _ in range(iters):
 pb.synchronize()
 wall = (time.perf_counter() - t0) / iters
 ms, flop, n = pb.kernel_time(False)
+# (the default form of the network — the convolution stack folded into one matrix — has one matrix launch, k_tail;
+# SF_POLICY_LAYERED=1 times the layer-by-layer form with its GEMM launches)
 print(json.dumps({"agents": B, "forward_ms": wall * 1e3, "gemm_ms_per_forward": ms / iters, "gemm_launches": n // iters,
-                  "gemm_tflops": flop / (ms * 1e-3) / 1e12, "flop_per_agent": flop / iters / B,
+                  "gemm_tflops": flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "flop_per_agent": flop / iters / B,
                   "agent_forwards_per_s": B / wall}))
 # the closed loop: observe -> forward -> act -> step
 t0 = time.perf_counter()
