@@ -1304,9 +1304,100 @@ __device__ inline void tail_tile(const float *in, int ldi, const float *W, const
   for (int r = 0; r < 4; ++r) out[(4 * g + r) * ldo + n0 + row] = acc[r] + bv;
 }
 
+// ---- k_tail's weight stream ----------------------------------------------------------------------------------
+// A wave's tiles follow each other — inside a layer and from layer to layer — and the weights do not depend on anything
+// the kernel computes.  They are fetched in batches of five k-steps (of 16: a K = 160 tile is two batches) into two
+// register buffers, always one batch ahead of the MFMAs: the second batch of a tile while its first is multiplied, the
+// first batch of the wave's NEXT tile — of this layer or, across the barriers and the row steps in between, of the next
+// one — while its second is.  What stays exposed is the very first batch of the kernel.  Same products in the same
+// order as tail_tile: the results are the same bits.
+constexpr int TS_U = 5;
+struct TsBuf {  // (passed and returned by value: every element stays a register)
+  f32x4 v[TS_U];
+};
+__device__ inline const float *ts_wp(const float *W, int K, int n0, int l) { return W + (size_t)(n0 + (l & 15)) * K + 4 * (l >> 4); }
+template <int N>
+__device__ inline TsBuf ts_issue(TsBuf b, const float *wp, int s0) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) b.v[u] = ldg4(wp + 16 * (s0 + u));
+  return b;
+}
+template <int N>
+__device__ inline void ts_mma(f32x4v &acc, const TsBuf &b, const float *ap, int s0) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(ap + 16 * (s0 + u));
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b.v[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b.v[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b.v[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b.v[u].w, acc, 0, 0, 0);
+  }
+}
+__device__ inline void ts_store(const f32x4v &acc, const float *bias, float *out, int ldo, int n0, int l) {
+  const int row = l & 15, g = l >> 4;
+  const float bv = bias ? bias[n0 + row] : 0.f;  // lane l holds column n0 + (l & 15) of agents 4 g .. 4 g + 3
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(4 * g + r) * ldo + n0 + row] = acc[r] + bv;
+}
+// one K = 160 tile: its first batch is already on its way in b0; `next(b0)` requests the wave's next tile's first batch
+template <class Next>
+__device__ inline void ts_tile160(const float *in, int ldi, const float *wp, const float *bias, float *out, int ldo, int n0, int l,
+                                  TsBuf &b0, TsBuf &b1, Next next) {
+  const float *ap = in + (l & 15) * ldi + 4 * (l >> 4);
+  b1 = ts_issue<5>(b1, wp, 5);
+  __builtin_amdgcn_sched_barrier(0);  // (the compiler would sink the loads to just in front of their MFMAs)
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  ts_mma<5>(acc, b0, ap, 0);
+  b0 = next(b0);
+  __builtin_amdgcn_sched_barrier(0);
+  ts_mma<5>(acc, b1, ap, 5);
+  ts_store(acc, bias, out, ldo, n0, l);
+}
+// the K = 352 tile of combined_processor: 22 k-steps as batches of 4 4 4 4 3 3 (an even number of batches: the next tile
+// starts in b0 again); its first batch (four k-steps) is already on its way in b0
+template <class Next>
+__device__ inline void ts_tile352(const float *in, int ldi, const float *wp, const float *bias, float *out, int ldo, int n0, int l,
+                                  TsBuf &b0, TsBuf &b1, Next next) {
+  static_assert(COMB_PAD == 16 * 22, "combined_processor's padded K");
+  const float *ap = in + (l & 15) * ldi + 4 * (l >> 4);
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  b1 = ts_issue<4>(b1, wp, 4);
+  __builtin_amdgcn_sched_barrier(0);
+  ts_mma<4>(acc, b0, ap, 0);
+  b0 = ts_issue<4>(b0, wp, 8);
+  __builtin_amdgcn_sched_barrier(0);
+  ts_mma<4>(acc, b1, ap, 4);
+  b1 = ts_issue<4>(b1, wp, 12);
+  __builtin_amdgcn_sched_barrier(0);
+  ts_mma<4>(acc, b0, ap, 8);
+  b0 = ts_issue<3>(b0, wp, 16);
+  __builtin_amdgcn_sched_barrier(0);
+  ts_mma<4>(acc, b1, ap, 12);
+  b1 = ts_issue<3>(b1, wp, 19);
+  __builtin_amdgcn_sched_barrier(0);
+  ts_mma<3>(acc, b0, ap, 16);
+  b0 = next(b0);
+  __builtin_amdgcn_sched_barrier(0);
+  ts_mma<3>(acc, b1, ap, 19);
+  ts_store(acc, bias, out, ldo, n0, l);
+}
+
+// k_tail's waves hand data to each other through LDS only: its barriers order LDS traffic and leave global loads and
+// stores (weights on their way, recurrent state on its way out) in flight
+__device__ __forceinline__ void tail_barrier() {
+#ifdef SF_TAIL_FULL_BARRIER
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+
 __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
   extern __shared__ __attribute__((aligned(16))) float tl[];
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  // (readfirstlane: the wave index is uniform, and the compiler should know — tile choices become scalar branches)
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = threadIdx.x & 63;
   const int a_raw = blockIdx.x * TL_R + w;
   const bool valid = a_raw < t.agents;
   const int a = valid ? a_raw : t.agents - 1;  // a ragged last workgroup computes its missing rows on the last agent, stores nothing
@@ -1343,19 +1434,38 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     }
     row_store(tl + TL_H1 + w * TL_LD, l, row_load(t.h[1] + (size_t)a * HID, l));
   }
-  __syncthreads();
-  if (t.feat) row_store(tl + TL_Y0 + w * TL_LD, l, row_load(t.feat + (size_t)a * HID, l));
-  else if (w < HID / 16) tail_tile<9 * HID>(tl + TL_A, TL_LDX, t.conv3_w, nullptr, tl + TL_Y0, TL_LD, 16 * w, l);  // Modules.hpp:66-71
-  __syncthreads();
+  // the weight stream (see ts_tile160): where each of this wave's tiles lives
+  TsBuf b0 = {}, b1 = {};
+  auto gru_wp = [&](int g, int tt) {
+    const int hh = tt >= G3 / 16, n0 = 16 * (tt - hh * (G3 / 16));
+    return ts_wp(hh ? t.gru_w_hh[g] : t.gru_w_ih[g], HID, n0, l);
+  };
+  auto res_wp = [&](int i, int tt) {
+    const int hd = tt >= HID / 16, n0 = 16 * (tt - hd * (HID / 16));
+    return ts_wp(t.res_w[hd][i], HID, n0, l);
+  };
+  if (t.feat) b0 = ts_issue<5>(b0, gru_wp(0, w), 0);  // (folded form: gru0's first tile is this wave's first)
+  tail_barrier();
+  if (t.feat) {
+    row_store(tl + TL_Y0 + w * TL_LD, l, row_load(t.feat + (size_t)a * HID, l));
+  } else {
+    if (w < HID / 16) tail_tile<9 * HID>(tl + TL_A, TL_LDX, t.conv3_w, nullptr, tl + TL_Y0, TL_LD, 16 * w, l);  // Modules.hpp:66-71
+    b0 = ts_issue<5>(b0, gru_wp(0, w), 0);
+  }
+  tail_barrier();
   row_store(tl + TL_B0 + w * TL_LD, l, row_norm(row_load(tl + TL_Y0 + w * TL_LD, l)));  // feat_n :108
-  __syncthreads();
+  tail_barrier();
   // ---- gru0: gi = W_ih feat_n + b_ih, gh = W_hh h0 + b_hh (30 + 30 tiles)                          :110-113
   for (int tt = w; tt < 2 * (G3 / 16); tt += TL_R) {
     const int hh = tt >= G3 / 16, n0 = 16 * (tt - hh * (G3 / 16));
-    tail_tile<HID>(tl + (hh ? TL_B1 : TL_B0), TL_LD, hh ? t.gru_w_hh[0] : t.gru_w_ih[0], hh ? t.gru_b_hh[0] : t.gru_b_ih[0],
-                   tl + (hh ? TL_GH : TL_GI), G3, n0, l);
+    ts_tile160(tl + (hh ? TL_B1 : TL_B0), TL_LD, gru_wp(0, tt), hh ? t.gru_b_hh[0] : t.gru_b_ih[0], tl + (hh ? TL_GH : TL_GI), G3, n0, l,
+               b0, b1, [&](TsBuf b) {
+                 if (tt + TL_R < 2 * (G3 / 16)) return ts_issue<5>(b, gru_wp(0, tt + TL_R), 0);
+                 if (w < HID / 16) return ts_issue<4>(b, ts_wp(t.comb_w, COMB_PAD, 16 * w, l), 0);  // next: combined_processor
+                 return ts_issue<5>(b, gru_wp(1, w), 0);                                            // (no tile there: gru1)
+               });
   }
-  __syncthreads();
+  tail_barrier();
   {  // gru cell, combined = [norm(h0') + feat_n | norm(pov) | 0]                                        :110-123
     const Row3 hn = gru_cell(tl + TL_GI + w * G3, tl + TL_GH + w * G3, row_load(tl + TL_B1 + w * TL_LD, l), l);
     if (valid) row_store(t.h[0] + (size_t)a * HID, l, hn);
@@ -1381,17 +1491,22 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     }
     row_store(tl + TL_B1 + w * TL_LD, l, row_load(tl + TL_H1 + w * TL_LD, l));  // h1 takes h0's place
   }
-  __syncthreads();
-  if (w < HID / 16) tail_tile<COMB_PAD>(tl + TL_COMB, TL_LDC, t.comb_w, t.comb_b, tl + TL_Y0, TL_LD, 16 * w, l);  // :125
-  __syncthreads();
+  tail_barrier();
+  if (w < HID / 16)                                                                                         // :125
+    ts_tile352(tl + TL_COMB, TL_LDC, ts_wp(t.comb_w, COMB_PAD, 16 * w, l), t.comb_b, tl + TL_Y0, TL_LD, 16 * w, l, b0, b1,
+               [&](TsBuf b) { return ts_issue<5>(b, gru_wp(1, w), 0); });
+  tail_barrier();
   row_store(tl + TL_B2 + w * TL_LD, l, row_norm(row_load(tl + TL_Y0 + w * TL_LD, l)));  // gated_n :126
-  __syncthreads();
+  tail_barrier();
   for (int tt = w; tt < 2 * (G3 / 16); tt += TL_R) {  // gru1                                             :128-131
     const int hh = tt >= G3 / 16, n0 = 16 * (tt - hh * (G3 / 16));
-    tail_tile<HID>(tl + (hh ? TL_B1 : TL_B2), TL_LD, hh ? t.gru_w_hh[1] : t.gru_w_ih[1], hh ? t.gru_b_hh[1] : t.gru_b_ih[1],
-                   tl + (hh ? TL_GH : TL_GI), G3, n0, l);
+    ts_tile160(tl + (hh ? TL_B1 : TL_B2), TL_LD, gru_wp(1, tt), hh ? t.gru_b_hh[1] : t.gru_b_ih[1], tl + (hh ? TL_GH : TL_GI), G3, n0, l,
+               b0, b1, [&](TsBuf b) {
+                 if (tt + TL_R < 2 * (G3 / 16)) return ts_issue<5>(b, gru_wp(1, tt + TL_R), 0);
+                 return ts_issue<5>(b, res_wp(0, w), 0);  // next: the first ResB layer
+               });
   }
-  __syncthreads();
+  tail_barrier();
   {  // out = norm(h1') + gated_n; both heads start from norm(out)
     const Row3 hn = gru_cell(tl + TL_GI + w * G3, tl + TL_GH + w * G3, row_load(tl + TL_B1 + w * TL_LD, l), l);
     if (valid) row_store(t.h[1] + (size_t)a * HID, l, hn);
@@ -1403,13 +1518,19 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     row_store(tl + TL_X0 + w * TL_LD, l, xn);
     row_store(tl + TL_X1 + w * TL_LD, l, xn);
   }
-  __syncthreads();
+  tail_barrier();
   for (int i = 0; i < 3; ++i) {  // ResB layers of the two heads                                           :41-48
     for (int tt = w; tt < 2 * (HID / 16); tt += TL_R) {
       const int hd = tt >= HID / 16, n0 = 16 * (tt - hd * (HID / 16));
-      tail_tile<HID>(tl + (hd ? TL_X1 : TL_X0), TL_LD, t.res_w[hd][i], t.res_b[hd][i], tl + (hd ? TL_LIN1 : TL_LIN0), TL_LD, n0, l);
+      ts_tile160(tl + (hd ? TL_X1 : TL_X0), TL_LD, res_wp(i, tt), t.res_b[hd][i], tl + (hd ? TL_LIN1 : TL_LIN0), TL_LD, n0, l, b0, b1,
+                 [&](TsBuf b) {
+                   if (tt + TL_R < 2 * (HID / 16)) return ts_issue<5>(b, res_wp(i, tt + TL_R), 0);
+                   if (i < 2) return ts_issue<5>(b, res_wp(i + 1, w), 0);
+                   if (w < 2) return ts_issue<5>(b, ts_wp(t.head_w[w], HID, 0, l), 0);  // next: the output layers
+                   return b;
+                 });
     }
-    __syncthreads();
+    tail_barrier();
 #pragma unroll
     for (int hd = 0; hd < 2; ++hd) {
       float *xp = tl + (hd ? TL_X1 : TL_X0) + w * TL_LD;
@@ -1419,12 +1540,14 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
       for (int q = 0; q < 3; ++q) r.v[q] = fmaxf(y.v[q], 0.f) + xv.v[q];
       row_store(xp, l, row_norm(r));
     }
-    __syncthreads();
+    tail_barrier();
   }
   // p = softmax(W_p x_p + b_p) + 1e-8, v = sigmoid(W_v x_v + b_v)                                           :172-175
   // (the two output layers as one MFMA tile each: weights padded with zero rows to 16 columns)
-  if (w < 2) tail_tile<HID>(tl + (w ? TL_X1 : TL_X0), TL_LD, t.head_w[w], t.head_b[w], tl + (w ? TL_LIN1 : TL_LIN0), TL_LD, 0, l);
-  __syncthreads();
+  if (w < 2)
+    ts_tile160(tl + (w ? TL_X1 : TL_X0), TL_LD, ts_wp(t.head_w[w], HID, 0, l), t.head_b[w], tl + (w ? TL_LIN1 : TL_LIN0), TL_LD, 0, l, b0, b1,
+               [&](TsBuf b) { return b; });
+  tail_barrier();
   if (valid) {
     const float *lg = tl + TL_LIN0 + w * TL_LD;
     float mx = lg[0];
