@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_heads(const float *xp, const float *xv,
 //                 owns 16-column tiles of the [16 agents][N] output; per 16 k it reads one float4 of its agent row
 //                 from LDS and one float4 of its weight row from global memory (lane l: row / column l & 15,
 //                 k = 4 (l >> 4) + j in MFMA j — any fixed permutation of k works as long as both operands use it),
-//                 weight loads kept two batches of ~10 float4 ahead
+//                 the weights of the wave's NEXT tile on their way while this one is multiplied (ts_tile160)
 //   row steps     one wave per agent, the row kernels' own functions (row_norm, gru_cell) on LDS rows
 // LDS rows that feed a matrix step are K + 8 floats apart: conflict-free for the ds_read_b128 lane groups.
 // ---------------------------------------------------------------------------------------------------------
