@@ -140,6 +140,12 @@ int sf_policy_gemm(sf_policy *p, const float *d_a, int32_t lda, const float *d_w
 int sf_policy_gemm_split(sf_policy *p, const float *d_a, int32_t lda, const float *d_w, const float *d_bias, float *d_c,
                          int32_t ldc, int32_t m, int32_t n, int32_t k);
 
+/* Test hook: GameCNN::forward alone (Modules.hpp:66-71) — the 160 features behind the four convolutions, before any
+ * normalisation — for agents [0, agents) from the dense observations d_obs, into d_feat [agents][160] (device).  The
+ * composed matrix by default, the four layers one after the other under SF_POLICY_LAYERED=1.  No recurrent state is
+ * touched. */
+int sf_policy_features(sf_policy *p, const float *d_obs, int32_t agents, float *d_feat);
+
 int sf_policy_abi_version(void);
 
 #ifdef __cplusplus

@@ -2096,6 +2096,27 @@ int sf_policy_forward(sf_policy *pp, const float *d_obs, int32_t agents, float *
   return sfp::forward(reinterpret_cast<Policy *>(pp), d_obs, agents, d_probs, d_value);
 }
 
+int sf_policy_features(sf_policy *pp, const float *d_obs, int32_t agents, float *d_feat) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  int rc = sfp::check_agents(p, agents);
+  if (rc) return rc;
+  if (!d_obs || !d_feat) return sfp::fail(SF_ERR_ARG, "null buffer");
+  SFP_HIP(hipSetDevice(p->device));
+  if (p->folded) {
+    const dim3 grid((unsigned)(agents < 4 * p->sk_blocks ? agents : 4 * p->sk_blocks));
+    hipLaunchKernelGGL(sfp::k_feat_dense, grid, dim3(sfp::FD_T), 0, p->stream, d_obs, p->fold, d_feat, agents, sfp::C0List{});
+  } else {
+    const dim3 c0_grid((unsigned)(agents < p->sk_blocks / 2 ? agents : p->sk_blocks / 2));
+    hipLaunchKernelGGL(sfp::k_conv0_sparse<false>, c0_grid, dim3(sfp::C0_T), sfp::C0_LDS, p->stream, d_obs, p->conv0_wt, p->act[0], agents,
+                       sfp::C0List{});
+    if ((rc = p->conv(p->act[0], p->conv_w[1], p->act[1], agents, 15, sfp::HID, 0, p->conv_w3[1]))) return rc;
+    if ((rc = p->conv(p->act[1], p->conv_w[2], p->act[2], agents, 7, sfp::HID, 0, p->conv_w3[2]))) return rc;
+    if ((rc = p->conv(p->act[2], p->conv_w[3], d_feat, agents, 3, sfp::HID, 0))) return rc;
+  }
+  SFP_HIP(hipGetLastError());
+  return SF_OK;
+}
+
 int sf_policy_forward_sparse(sf_policy *pp, const uint32_t *d_keys, const float *d_vals, const uint32_t *d_counts,
                              const float *d_pov, int32_t cap, int32_t agents, float *d_probs, float *d_value) {
   Policy *p = reinterpret_cast<Policy *>(pp);

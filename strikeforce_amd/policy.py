@@ -123,6 +123,7 @@ def _bind(L):
     L.sf_policy_synchronize.argtypes = [vp]
     L.sf_policy_gemm.argtypes = [vp, vp, C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.sf_policy_gemm_split.argtypes = L.sf_policy_gemm.argtypes
+    L.sf_policy_features.argtypes = [vp, vp, C.c_int32, vp]
     L.sf_policy_kernel_time.argtypes = [vp, C.c_int32, _FP, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.sf_policy_kernel_time_ex.argtypes = L.sf_policy_kernel_time.argtypes
     for n in EXPORTS:
@@ -136,7 +137,7 @@ EXPORTS = ["sf_policy_create", "sf_policy_destroy", "sf_policy_reset_memory", "s
            "sf_policy_forward_sparse_or_dense",
            "sf_policy_sparse_overflows", "sf_policy_act",
            "sf_policy_get_memory", "sf_policy_set_memory", "sf_policy_set_stream", "sf_policy_synchronize",
-           "sf_policy_kernel_time", "sf_policy_kernel_time_ex", "sf_policy_kernel_time_by_kernel", "sf_policy_gemm", "sf_policy_gemm_split", "sf_policy_abi_version"]
+           "sf_policy_kernel_time", "sf_policy_kernel_time_ex", "sf_policy_kernel_time_by_kernel", "sf_policy_gemm", "sf_policy_gemm_split", "sf_policy_features", "sf_policy_abi_version"]
 
 
 class PolicyBatch:
@@ -257,6 +258,10 @@ class PolicyBatch:
         self._ck(self.L.sf_policy_gemm(self.h, C.c_void_p(d_a_ptr), lda, C.c_void_p(d_w_ptr),
                                        C.c_void_p(d_bias_ptr) if d_bias_ptr else None, C.c_void_p(d_c_ptr), ldc, m, n, k),
                  "sf_policy_gemm")
+
+    def features(self, d_obs_ptr, agents, d_feat_ptr):
+        """GameCNN::forward alone: [agents][160] features behind the four convolutions (test hook)."""
+        self._ck(self.L.sf_policy_features(self.h, C.c_void_p(d_obs_ptr), agents, C.c_void_p(d_feat_ptr)), "sf_policy_features")
 
     def gemm_split(self, d_a_ptr, lda, d_w_ptr, d_bias_ptr, d_c_ptr, ldc, m, n, k):
         """The same product through the bf16-split kernel of conv1 / conv2 (six bf16 MFMAs per block, f32-level error)."""

@@ -272,6 +272,45 @@ def test_split_and_f32_convolutions_agree():
     assert not np.array_equal(out[0][0], out[1][0])  # two different kernels did run
 
 
+def test_the_convolution_stack_alone_matches_float64(cnn):
+    """GameCNN::forward alone (sf_policy_features): the 160 features behind the four bias-free convolutions against the
+    same chain in float64, on sparse inputs (1 % non-zero, what an observation is), dense ones (30 %) and single
+    non-zeros in the window's corners, on its edges and inside (one row of the composed matrix each: every boundary
+    case of the 3x3 / stride-2 windows).  Two gates: |err| <= 1e-8 * (the chain applied to |x| with |W|: what the
+    roundings of a four-layer f32 evaluation are proportional to; measured 2e-10 composed, 2e-9 layered), and |err| <=
+    c * the agent's largest feature, c = 2e-6 for the composed matrix (its entries are within half an ulp of the exact
+    composition; ~20-term f32 partial sums, combined in f64) and 1e-5 for the four layers one after the other."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(77)
+    params = policy.init_parameters(seed=31)
+    B = 48
+    x = np.zeros((B, 32, 31, 31), dtype=np.float32)
+    x[:32] = rng.uniform(-2.0, 2.0, size=(32, 32, 31, 31)) * (rng.uniform(size=(32, 32, 31, 31)) < 0.01)
+    x[32:40] = rng.uniform(-2.0, 2.0, size=(8, 32, 31, 31)) * (rng.uniform(size=(8, 32, 31, 31)) < 0.3)
+    for b, (ch, y, xx) in enumerate([(0, 0, 0), (31, 30, 30), (5, 0, 30), (7, 30, 0), (3, 15, 15), (9, 1, 2), (10, 2, 1), (11, 29, 28)]):
+        x[40 + b, ch, y, xx] = 1.5
+    want = torch.from_numpy(x).double()
+    mag = want.abs()
+    for i in range(4):
+        w = torch.from_numpy(params["backbone.cnn.conv%d.weight" % i]).double()
+        want, mag = F.conv2d(want, w, stride=2), F.conv2d(mag, w.abs(), stride=2)
+    want, mag = want.reshape(B, 160).numpy(), mag.reshape(B, 160).numpy()
+    pb = policy.PolicyBatch(params, B)
+    d_obs = _dev(x)
+    d_feat = torch.zeros((B, 160), dtype=torch.float32, device="cuda")
+    pb.features(d_obs.data_ptr(), B, d_feat.data_ptr())
+    pb.synchronize()
+    got = d_feat.cpu().numpy().astype(np.float64)
+    pb.close()
+    err = np.abs(got - want)
+    scale = np.abs(want).max(axis=1, keepdims=True)  # an agent's largest feature
+    print("%s: worst |err| / magnitude %.3g, / the agent's largest feature %.3g" %
+          (cnn, float(np.max(err / np.maximum(mag, 1e-30))), float(np.max(err / scale))))
+    assert (err <= 1e-8 * mag + 1e-30).all()
+    assert (err <= (2e-6 if cnn == "folded" else 1e-5) * scale).all()
+    assert np.abs(want[40:]).max() > 1e-4  # the single non-zeros do reach the features
+
+
 def test_folded_and_layered_convolutions_agree():
     """The convolution stack as one composed matrix on the non-zeros (default) and layer by layer (SF_POLICY_LAYERED=1) on
     real observations of the simulator, over recurrent steps: same probabilities, value and state within this file's
