@@ -26,7 +26,9 @@ def test_branch_coverage_of_the_parity_configs():
     for name, arenas, steps in (("C3", 4, 700), ("STRESS", 6, 900)):
         for k, v in _run(name, arenas, steps).items():
             total[k] = total.get(k, 0) + v
-    missing = [k for k, v in total.items() if v == 0]
+    # (credit_slot_reused — a hit credited to the newcomer in a dead owner's slot, App. E-11 — needs a bullet that outlives
+    # its owner and a spawn in between: scripted in tests/test_order_scenarios.py, never met by random play)
+    missing = [k for k, v in total.items() if v == 0 and k != "credit_slot_reused"]
     assert not missing, "branches never taken: %s" % missing
 
 

@@ -398,6 +398,68 @@ def test_squad_needs_kills_and_dead_rivals(impl):
     assert (d.hdr.done, d.hdr.outcome) == (1, abi.DIED)
 
 
+# ---- a hit is credited to whoever holds the owner's slot now (App. E-11) ------------------------------------------------------
+def slot_reuse_world():
+    """Two corridors, columns 1 and 3 (rows 1..28), joined along row 28; everything else wall."""
+    opened = [(0, r, 1) for r in range(1, 29)] + [(0, r, 3) for r in range(1, 29)] + [(0, 28, 2)]
+    return world(opened, abi.MODE_SOLO, 1, player=ref_player(), H=6, Z=4, B=48, P=4)
+
+
+def slot_reuse_script(shoot, steps=66):
+    """The player: down its corridor (27 steps), over to the foot of the other one (2), facing up (turn_l twice,
+    Character.hpp:752-758), AK_47 in hand ('m'), one shot at step `shoot`, waiting otherwise."""
+    script = ["s"] * 27 + ["d", "d", "q", "q", "m"]
+    script += ["+"] * (steps - len(script))
+    script[shoot] = "x"
+    return script
+
+
+@pytest.mark.parametrize("impl", IMPLS_REF)
+def test_a_hit_is_credited_to_whoever_holds_the_owners_slot_now(impl):
+    """Solo, the level-10 account.  A bullet's owner is a `Human*` into hum[] (gameplay.hpp:613, Item.hpp:156-157), so a
+    hit is credited to whoever holds that SLOT when it lands (App. E-11).  The world is two corridors joined at the
+    bottom; the seed puts the NPC human of the first loop top into the right-hand one, at (12,3) (found by
+    tests/tools/find_slot_reuse_credit.py; NPC humans never turn — human_rnpc_bot has no 'q' / 'e', gameplay.hpp:1927-1940 —
+    so it fires its gun down the corridor whenever its draw says 'x').  The player walks round to the corridor's foot,
+    (28,3), turns up and fires ONE shot at step 35 (damage 1075): it reaches the NPC at step 43, Hp 1000 - 1075, the
+    player's kill.  The NPC's last bullet (damage 350, effect -125) is then still on its way down.  The spawn of frame
+    101 (the loop top behind step 49, gameplay.hpp:1448-1449) finds a free cell, (1,3), and h_ind() hands out the lowest
+    free slot, the dead NPC's (gameplay.hpp:215-221): a fresh NPC — Hp 1000, nothing to its name, no weapon in hand
+    (it cannot have hit anybody).  In step 51 the old bullet reaches the player: Hp -350, mindamage -125 — and the
+    350 / -125 go onto the account of the NEWCOMER in slot 1."""
+    tb, shoot = 1700051496, 35
+    w = slot_reuse_world()
+    s = make(impl, w, tb, player=ref_player())
+    d = s.dump()
+    npc = d.humans[1]
+    assert (npc.alive, npc.r, npc.c, npc.rnpc, npc.team, npc.hp, npc.way) == (1, 12, 3, 1, 0, 1000, 1)
+    snap = {}
+    for n, ch in enumerate(slot_reuse_script(shoot, steps=53)):
+        snap[n] = d = s.step(ch)
+        assert sum(z.alive for z in d.zombies) == 0 and sum(h.alive for h in d.humans) <= 2, n
+        assert not (s.r.ended if isinstance(s, RefSim) else d.hdr.done), n  # one kill of the five a level-1 Solo game needs
+    me = lambda n: snap[n].humans[0]
+    one = lambda n: snap[n].humans[1]
+    flying = lambda n: sorted((b.r, b.c, b.way, b.damage, b.owner) for b in snap[n].bullets if b.alive)
+    assert (me(34).r, me(34).c, me(34).way, me(34).vec, me(34).ind) == (28, 3, 3, 2, 4)
+    assert (26, 3, 3, 1075, 1) in flying(35)                                   # the player's shot, two cells up already
+    assert one(42).alive == 1 and flying(42) == [(12, 3, 3, 1075, 1)]           # one cell below the NPC, (11,3)
+    assert (one(43).alive, one(43).hp) == (0, 1000 - 1075)
+    assert (me(43).kills, me(43).damage, snap[43].hdr.kills) == (1, 1075, 1)
+    old = (one(43).damage, one(43).effect, one(43).kills)                       # what the dead NPC's own hits had earned it
+    assert old == (4 * 350, 4 * -125, 0)
+    assert flying(48) == [(23, 3, 1, 350, 2)] and one(48).alive == 0           # its last bullet, owner = slot 1
+    assert (one(48).damage, one(48).effect) == old[:2]
+    new = one(49)                                                               # the loop top behind step 49: frame 101
+    assert (new.alive, new.r, new.c, new.hp, new.damage, new.effect, new.kills, new.vec, new.rnpc) == (1, 1, 3, 1000, 0, 0, 0, -1, 1)
+    assert flying(50) == [(27, 3, 1, 350, 2)] and (me(50).hp, me(50).mindamage) == (me(49).hp, me(49).mindamage)
+    assert flying(51) == [] and (me(51).hp, me(51).mindamage) == (me(50).hp - 350, me(50).mindamage - 125)
+    assert (one(51).damage, one(51).effect, one(51).kills, one(51).vec) == (350, -125, 0, -1)   # credited to the newcomer
+    if impl is Oracle:
+        assert s.sim.events()["credit_slot_reused"] == 1
+    close(s)
+
+
 # ---- the NPC policy's draw paths ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("impl", IMPLS_REF)
 def test_npc_humans_draw_one_or_three_times_and_pick_weapons_on_the_fiftieth_frame(impl):

@@ -133,8 +133,10 @@ def test_squad_on_a_small_three_floor_world():
 
 def test_every_tick_branch_was_met_in_the_pinned_runs():
     """The oracle's branch counters summed over the runs above: the comparison saw every kind of event the tick path
-    has (`episode_end`: tests/test_ref_check_end.py plays games to their end)."""
+    has (`episode_end`: tests/test_ref_check_end.py plays games to their end; `credit_slot_reused`, a hit credited to the
+    newcomer in a dead owner's slot, needs a bullet that outlives its owner AND a spawn in between: scripted, and played by
+    the reference too, in tests/test_order_scenarios.py::test_a_hit_is_credited_to_whoever_holds_the_owners_slot_now)."""
     if len(EVENTS) == 0:
         pytest.skip("runs after the lock-step tests of this module")
-    missing = [k for k, v in EVENTS.items() if v == 0 and k != "episode_end"]
+    missing = [k for k, v in EVENTS.items() if v == 0 and k not in ("episode_end", "credit_slot_reused")]
     assert not missing, (missing, EVENTS)
