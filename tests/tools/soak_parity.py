@@ -1,14 +1,14 @@
-"""Soak: the HIP path against the oracle at the size bench.py reports, far longer than the test suite runs — every arena's
+"""TEST INFRASTRUCTURE (uses the oracle / the reference build as the checker).  Soak: the HIP path against the oracle at the size bench.py reports, far longer than the test suite runs — every arena's
 digest at several checkpoints of a long run (launches of 100 steps: the launch order by population is renewed on the way,
 Timer episodes run out and restart on the seed the 4096-arena run gives them).  One JSON line per configuration.
-Usage (GPU box): python tools/soak_parity.py [C3:4000 C2:4000 C4:600 C5:300]"""
+Usage (GPU box): python tests/tools/soak_parity.py [C3:4000 C2:4000 C4:600 C5:300]"""
 import json
 import multiprocessing as mp
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

@@ -1,13 +1,13 @@
-"""Soak: the HIP network (both forms of its convolution stack) against the REFERENCE's own AgentModel
+"""TEST INFRASTRUCTURE (uses the oracle / the reference build as the checker).  Soak: the HIP network (both forms of its convolution stack) against the REFERENCE's own AgentModel
 (oracle/_ref/libsf_refmodules.so: bots/bot-0.5/Modules.hpp:26-180 compiled unedited, one model object per agent as the
 reference has one Agent per human) on the GPU simulator's own observations, over a recurrent closed loop: every step the
 reference models and the HIP batch see the same observation and are fed the same (arg-max) action.  Prints one JSON line per
-form with the worst differences.  Usage (GPU box; the .so travels with the snapshot): python tools/soak_policy.py [agents] [steps]"""
+form with the worst differences.  Usage (GPU box; the .so travels with the snapshot): python tests/tools/soak_policy.py [agents] [steps]"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
