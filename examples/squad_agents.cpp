@@ -58,7 +58,8 @@ int main(int argc, char **argv) {
   sf_config cfg;
   sf_config_defaults(&cfg);
   cfg.arenas = 1, cfg.floors = 3, cfg.rows = 30, cfg.cols = 100;  // gameplay.hpp:37
-  cfg.cap_humans = 64, cfg.cap_zombies = 64, cfg.cap_bullets = 256, cfg.cap_portals = 32, cfg.cap_chests = 9000;
+  // pools for a whole game of the reference (its own hold 9000): 1024 zombies and 512 exits live in the arena's LDS
+  cfg.cap_humans = 64, cfg.cap_zombies = 1024, cfg.cap_bullets = 256, cfg.cap_portals = 512, cfg.cap_chests = 9000;
   cfg.mode = SF_MODE_SQUAD, cfg.level = 2, cfg.n_agents = 10, cfg.auto_reset = 0;
   cfg.timer_frames_per_level = 1 << 20;
   // the reference's level-10 account (accounts/game/1): 15000 Hp, 1000 mindamage, one of everything

@@ -83,9 +83,12 @@ int sf_policy_forward(sf_policy *p, const float *d_obs, int32_t agents, float *d
 /* sf_policy_forward on the observation in list form (sf_observe_sparse_device: d_keys / d_vals [agents][cap],
  * d_counts [agents], d_pov [agents][160]): the convolution stack takes the non-zeros as they come instead of scanning a
  * dense 123 KB buffer per agent for them, and the five centre cells come from d_pov.  Same results as the dense call,
- * bit for bit (same values applied in the same order).  An agent whose count exceeds cap or 2048, or is the
- * 0xffffffff marker, is evaluated on an empty observation and counted: sf_policy_sparse_overflows() returns (and
+ * bit for bit (same values applied in the same order).  cap is at most SF_POLICY_LIST_MAX (SF_ERR_ARG otherwise): with
+ * that, "the list did not fit" means the same here as in sf_observe_overflow_device — count > cap, or the 0xffffffff
+ * marker — and the two libraries never disagree about which agents fall back to the dense row.  Such an agent is
+ * evaluated on an empty observation and counted: sf_policy_sparse_overflows() returns (and
  * clears) that count — non-zero means the caller should have taken the dense pair of calls for that step. */
+#define SF_POLICY_LIST_MAX 2048 /* an observation of the BASELINE configurations has ~250-300 non-zeros */
 int sf_policy_forward_sparse(sf_policy *p, const uint32_t *d_keys, const float *d_vals, const uint32_t *d_counts,
                              const float *d_pov, int32_t cap, int32_t agents, float *d_probs, float *d_value);
 /* The same with a dense fallback, so that no agent is ever evaluated on a blank window: the agents whose list did not

@@ -138,7 +138,9 @@ BENCH_DIMS = (1, 64, 64, 8, 24, 64, 9000)  # BASELINE.json configs[2]: 64x64, H8
 # bullet pool of tests/test_order_scenarios.py): the
 # default call compiles them too, side by side, so that the first test run does not compile them one after the other
 TEST_DIMS = [(1, 32, 32, 1, 4, 16, 9000), (1, 64, 64, 1, 16, 32, 9000), (1, 24, 40, 6, 12, 5, 6),
-             (1, 28, 36, 12, 10, 48, 9000), (3, 20, 30, 12, 10, 32, 9000), (3, 30, 100, 12, 4, 1, 4)]
+             (1, 28, 36, 12, 10, 48, 9000), (3, 20, 30, 12, 10, 32, 9000), (3, 30, 100, 12, 4, 1, 4),
+             # configs[3] / configs[4]'s dimensions: the maps whose flag plane the device keeps in HBM (k_step<., true, .>)
+             (1, 128, 128, 10, 20, 64, 9000), (1, 256, 256, 8, 56, 128, 9000)]
 
 
 def binary_for(dims=None, squad_agents=False):

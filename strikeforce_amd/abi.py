@@ -11,9 +11,9 @@ OBS_WINDOW = 31
 OBS_FLOATS = OBS_CHANNELS * OBS_WINDOW * OBS_WINDOW  # 30752, bots/bot-0.5/Custom.hpp:137-159
 
 MAX_HUMANS = 64
-MAX_ZOMBIES = 64
+MAX_ZOMBIES = 9000
 MAX_BULLETS = 256
-MAX_PORTALS = 64
+MAX_PORTALS = 9000
 MAX_AGENTS = 16
 
 MODE_SOLO, MODE_TIMER, MODE_SQUAD, MODE_BATTLE = 0, 1, 2, 3

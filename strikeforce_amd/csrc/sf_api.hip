@@ -31,42 +31,42 @@ __device__ uint32_t sf_diag_buffer[16 * 65536];  // diagnostic build only: [aren
 
 // HP (HBM_PLANE): maps whose flag plane is too large for LDS keep it in HBM (sf_core.hpp).  BM (BITMAPS): the cell
 // bitmaps fit in LDS (every LDS-plane map, and HBM-plane maps up to 128 x 128).  Variants built: (HP 0, BM 1),
-// (HP 1, BM 1), (HP 1, BM 0).
-template <int NB, bool HP, bool BM>
+// (HP 1, BM 1), (HP 1, BM 0).  ZL (large pools): zombie / exit tables of more than 64 slots in LDS; built for NB = 4 only.
+template <int NB, bool HP, bool BM, bool ZL>
 __global__ __launch_bounds__(64) void k_reset(Params p, const uint64_t *tb, const uint64_t *serial) {
   extern __shared__ __attribute__((aligned(2048))) uint8_t lds[];  // the RNG power table comes first (W::pow_pair)
-  Core<WaveGfx950, NB, HP, BM>::reset_body(lds, p, (int)blockIdx.x, tb, serial);
+  Core<WaveGfx950, NB, HP, BM, ZL>::reset_body(lds, p, (int)blockIdx.x, tb, serial);
 }
 
-template <int NB, bool HP, bool BM>
+template <int NB, bool HP, bool BM, bool ZL>
 __global__ __launch_bounds__(64) void k_step(Params p, const uint8_t *cmds, int k) {
   extern __shared__ __attribute__((aligned(2048))) uint8_t lds[];  // the RNG power table comes first (W::pow_pair)
   const int a = p.perm ? (int)gptr(p.perm)[blockIdx.x] : (int)blockIdx.x;
-  Core<WaveGfx950, NB, HP, BM>::step_body(lds, p, a, cmds, k);
+  Core<WaveGfx950, NB, HP, BM, ZL>::step_body(lds, p, a, cmds, k);
 }
 
 // Launch order for k_step: arenas by population (live zombies + live humans as the last store() recorded them, SC_LOAD),
 // in SNAKE order — blocks of 1024 alternately descending and ascending.  A step's cost grows with the arena's population
-// and a launch ends with its slowest wavefront; the dispatcher hands consecutive workgroups to different SIMDs, so with
-// this order the four arenas that share a SIMD are one of each load quartile with about equal sums per SIMD, the busiest
-// arenas start first, and a busy arena's neighbours finish early and leave it the SIMD.  Measured on configs[2] (same-call
-// A/B, tools/r03_balance_ab.sh): 186.7 -> 204.8 M env-steps/s, 20-step launches 172 -> 189 M; configs[1] (all arenas at
-// the zombie cap: nothing to order) unchanged; keyed by the arena's measured cycles per step instead: +1.6 % only (an
-// arena's time depends on its neighbours, so that key chases itself).  One workgroup; a counting sort over 65 classes,
-// ties in any order: arenas are independent, the order never shows in any result.
-__global__ __launch_bounds__(1024) void k_rank(Params p, uint16_t *perm) {
+// and a launch ends with its slowest wavefront; the chip has 1024 SIMDs and the dispatcher hands consecutive workgroups
+// to different ones, so with this order the arenas that share a SIMD are one of each load class with about equal sums
+// per SIMD, the busiest arenas start first, and a busy arena's neighbours finish early and leave it the SIMD.  Measured
+// on configs[2] (same-call A/B, tools/r03_balance_ab.sh): 186.7 -> 204.8 M env-steps/s, 20-step launches 172 -> 189 M;
+// configs[1] (all arenas at the zombie cap: nothing to order) unchanged; keyed by the arena's measured cycles per step
+// instead: +1.6 % only (an arena's time depends on its neighbours, so that key chases itself).  Other arena counts and
+// the HBM-plane maps: profiles/r04_rank_sweep.txt.
+// One workgroup, any number of arenas (each thread walks arenas t, t + 1024, ...); a counting sort over 65 classes, ties
+// in any order: arenas are independent, the order never shows in any result.  A last block of fewer than 1024 arenas
+// keeps the direction of a full one (its lightest arenas meet the SIMDs that got the busiest of the block before).
+__global__ __launch_bounds__(1024) void k_rank(Params p, uint32_t *perm) {
   __shared__ uint32_t hist[72];
   const int t = (int)threadIdx.x;
   if (t < 72) hist[t] = 0u;
   __syncthreads();
-  uint32_t cls[4];  // A <= 4096: at most four arenas per thread
-  int cnt = 0;
-  for (int a = t; a < p.A && cnt < 4; a += 1024) {
-    uint32_t n = (uint32_t)gptr(p.scal)[(size_t)a * SC_WORDS + SC_LOAD];
-    n = n > 64u ? 64u : n;
-    cls[cnt++] = 64u - n;  // class 0 = the busiest
-    atomicAdd(&hist[64u - n], 1u);
-  }
+  auto cls_of = [&](int a) {
+    const uint32_t n = (uint32_t)gptr(p.scal)[(size_t)a * SC_WORDS + SC_LOAD];
+    return 64u - (n > 64u ? 64u : n);  // class 0 = the busiest
+  };
+  for (int a = t; a < p.A; a += 1024) atomicAdd(&hist[cls_of(a)], 1u);
   __syncthreads();
   if (t == 0) {
     uint32_t run = 0;
@@ -77,19 +77,21 @@ __global__ __launch_bounds__(1024) void k_rank(Params p, uint16_t *perm) {
     }
   }
   __syncthreads();
-  cnt = 0;
-  for (int a = t; a < p.A && cnt < 4; a += 1024) {
-    uint32_t pos = atomicAdd(&hist[cls[cnt++]], 1u);  // rank, busiest first
-    if (p.A == 4096 && ((pos >> 10) & 1u)) pos = (pos & ~1023u) | (1023u - (pos & 1023u));  // every second block backwards
-    gptr(perm)[pos] = (uint16_t)a;
+  for (int a = t; a < p.A; a += 1024) {
+    uint32_t pos = atomicAdd(&hist[cls_of(a)], 1u);  // rank, busiest first
+    if ((pos >> 10) & 1u) {  // every second block of 1024 backwards
+      const uint32_t base = pos & ~1023u, len = (uint32_t)p.A - base < 1024u ? (uint32_t)p.A - base : 1024u;
+      pos = base + (len - 1u - (pos - base));
+    }
+    gptr(perm)[pos] = (uint32_t)a;
   }
 }
 
 // sf_step_begin / sf_step_end: one half of one iteration (sf_core.hpp step<1> / step<2>)
-template <int NB, bool HP, bool BM>
+template <int NB, bool HP, bool BM, bool ZL>
 __global__ __launch_bounds__(64) void k_step_half(Params p, const uint8_t *cmds, int phase) {
   extern __shared__ __attribute__((aligned(2048))) uint8_t lds[];
-  Core<WaveGfx950, NB, HP, BM>::step_half_body(lds, p, (int)blockIdx.x, cmds, phase);
+  Core<WaveGfx950, NB, HP, BM, ZL>::step_half_body(lds, p, (int)blockIdx.x, cmds, phase);
 }
 
 // Human::active_agent of every commanded human (sf_agent_alive): alive and still driven through sf_step
@@ -132,6 +134,11 @@ static __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+constexpr int OBS_Z_STAGE = 256;    // zombie tables up to this many slots are staged in LDS with the other entities
+static inline size_t obs_lds_bytes(const Params &p) {
+  return (size_t)(HW_WORDS * p.H + (p.Z <= OBS_Z_STAGE ? ZW_WORDS * p.Z : 0) + BW_WORDS * p.B) * sizeof(uint32_t) + sizeof(int32_t) * 12 +
+         sizeof(Derived) * (size_t)(p.npc_block + 1);
+}
 constexpr int OBS_CLASS_RECS = 8;   // shared records of plain static cells: '#', '^', 'v', 'O', chest types 0-3
 constexpr int OBS_REC_MAX = 72;     // + cells with an entity or a player-built object on them (own record each)
 constexpr int OBS_LIST_MAX = 256;  // (a) values that need a real pow, (b) overflow cells' outputs
@@ -225,7 +232,8 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
     }
     return;
   }
-  const int nh = HW_WORDS * p.H, nz = ZW_WORDS * p.Z, nb = BW_WORDS * p.B;
+  const bool zstage = p.Z <= OBS_Z_STAGE;  // a larger zombie table is read where it lies (flat loads through ObsView)
+  const int nh = HW_WORDS * p.H, nz = zstage ? ZW_WORDS * p.Z : 0, nb = BW_WORDS * p.B;
   uint32_t *tab_lds = ent + nh + nz + nb;
   for (int i = tid; i < nh; i += OBS_THREADS) ent[i] = gptr(p.hum)[((size_t)(i / p.H) * p.A + a) * p.H + i % p.H];
   for (int i = tid; i < nz; i += OBS_THREADS) ent[nh + i] = gptr(p.zom)[((size_t)(i / p.Z) * p.A + a) * p.Z + i % p.Z];
@@ -251,7 +259,11 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   lds_barrier();
   // ---- pass 2 ----------------------------------------------------------------------------------------------
   ObsView v(p, 0);  // the LDS copy: one arena, [field][slot]
-  v.hum_ = ent, v.zom_ = ent + nh, v.bul_ = ent + nh + nz, v.A = 1;
+  v.hum_ = ent, v.bul_ = ent + nh + nz, v.A = 1;
+  if (zstage)
+    v.zom_ = ent + nh, v.zA = 1, v.za = 0;
+  else
+    v.zom_ = p.zom, v.zA = p.A, v.za = a;
   v.tab = reinterpret_cast<const Tables *>(tab_lds);
   for (int e = tid; e < p.H + p.Z + p.B; e += OBS_THREADS) {
     int s = -1;
@@ -261,11 +273,11 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
     } else if (e < p.H + p.Z) {
       const int z = e - p.H;
       const uint32_t zp = v.zom(ZW_POS, z);
-      if (zp & ZF_ALIVE) s = obs_window_slot(zp & POS_MASK, center), bits = (uint32_t)(z + 1) << 8;
+      if (zp & ZF_ALIVE) s = obs_window_slot(zp & POS_MASK, center), bits = (uint32_t)(z + 1) << OCC_Z_SH;
     } else {
       const int b = e - p.H - p.Z;
       const uint32_t ba = v.bul(BW_A, b);
-      if (ba & BA_REF) s = obs_window_slot(ba & POS_MASK, center), bits = (uint32_t)(b + 1) << 16;
+      if (ba & BA_REF) s = obs_window_slot(ba & POS_MASK, center), bits = (uint32_t)(b + 1) << OCC_B_SH;
     }
     if (s >= 0) atomicOr(&occ[s], bits);
   }
@@ -525,39 +537,41 @@ struct HipRT {
     return SF_OK;
   }
 
-  template <int NB>
+  // one launcher per kernel: picks the (HP, BM) variant by the map's size, sets the LDS attribute, launches
+  template <int NB, bool ZL>
   int do_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
-    const size_t lds = lds_bytes_for(p.cells_pad, p.lds_tab);
+    const size_t lds = lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P);
+    int rc;
     if (!hbm_plane(p.cells_pad)) {
-      int rc = lds_attr(k_reset<NB, false, true>, lds);
-      if (rc) return rc;
-      hipLaunchKernelGGL((k_reset<NB, false, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, tb, serial);
+      if ((rc = lds_attr(k_reset<NB, false, true, ZL>, lds))) return rc;
+      hipLaunchKernelGGL((k_reset<NB, false, true, ZL>), dim3((unsigned)p.A), dim3(64), lds, stream, p, tb, serial);
     } else if (use_bitmaps(p.cells_pad)) {
-      hipLaunchKernelGGL((k_reset<NB, true, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, tb, serial);
+      if ((rc = lds_attr(k_reset<NB, true, true, ZL>, lds))) return rc;
+      hipLaunchKernelGGL((k_reset<NB, true, true, ZL>), dim3((unsigned)p.A), dim3(64), lds, stream, p, tb, serial);
     } else {
-      hipLaunchKernelGGL((k_reset<NB, true, false>), dim3((unsigned)p.A), dim3(64), lds, stream, p, tb, serial);
+      if ((rc = lds_attr(k_reset<NB, true, false, ZL>, lds))) return rc;
+      hipLaunchKernelGGL((k_reset<NB, true, false, ZL>), dim3((unsigned)p.A), dim3(64), lds, stream, p, tb, serial);
     }
     SF_HIP(hipGetLastError());
     return SF_OK;
   }
   int launch_reset(const Params &p, int NB, const uint64_t *tb, const uint64_t *serial) {
     SF_HIP(hipSetDevice(device));
+    if (large_pools(p.Z, p.P)) return do_reset<4, true>(p, tb, serial);
     switch (NB) {
-      case 1: return do_reset<1>(p, tb, serial);
-      case 2: return do_reset<2>(p, tb, serial);
-      case 3: return do_reset<3>(p, tb, serial);
-      default: return do_reset<4>(p, tb, serial);
+      case 1: return do_reset<1, false>(p, tb, serial);
+      case 2: return do_reset<2, false>(p, tb, serial);
+      case 3: return do_reset<3, false>(p, tb, serial);
+      default: return do_reset<4, false>(p, tb, serial);
     }
   }
 
-  template <int NB>
+  template <int NB, bool ZL>
   int do_step(const Params &p, const uint8_t *cmds, int k) {
     const bool hp = hbm_plane(p.cells_pad), bm = use_bitmaps(p.cells_pad);
-    const size_t lds = lds_bytes_for(p.cells_pad, p.lds_tab);
-    if (!hp) {
-      int rc = lds_attr(k_step<NB, false, true>, lds);
-      if (rc) return rc;
-    }
+    const size_t lds = lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P);
+    int rc = !hp ? lds_attr(k_step<NB, false, true, ZL>, lds) : bm ? lds_attr(k_step<NB, true, true, ZL>, lds) : lds_attr(k_step<NB, true, false, ZL>, lds);
+    if (rc) return rc;
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (timing) {
       if (used_events == events.size()) {
@@ -569,55 +583,65 @@ struct HipRT {
       ev = &events[used_events++];
       SF_HIP(hipEventRecord(ev->first, stream));
     }
+    if (rank_pending) {
+      hipLaunchKernelGGL(k_rank, dim3(1), dim3(1024), 0, stream, p, rank_pending);
+      rank_pending = nullptr;
+      SF_HIP(hipGetLastError());
+    }
     if (!hp)
-      hipLaunchKernelGGL((k_step<NB, false, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, k);
+      hipLaunchKernelGGL((k_step<NB, false, true, ZL>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, k);
     else if (bm)
-      hipLaunchKernelGGL((k_step<NB, true, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, k);
+      hipLaunchKernelGGL((k_step<NB, true, true, ZL>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, k);
     else
-      hipLaunchKernelGGL((k_step<NB, true, false>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, k);
+      hipLaunchKernelGGL((k_step<NB, true, false, ZL>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, k);
     SF_HIP(hipGetLastError());
     if (ev) SF_HIP(hipEventRecord(ev->second, stream));
     return SF_OK;
   }
   bool can_rank() const { return true; }
-  int launch_rank(const Params &p, uint16_t *perm) {
-    SF_HIP(hipSetDevice(device));
-    hipLaunchKernelGGL(k_rank, dim3(1), dim3(1024), 0, stream, p, perm);
-    SF_HIP(hipGetLastError());
+  // k_rank runs right in front of the k_step launch it orders, inside that launch's pair of timing events: what
+  // sf_kernel_time reports (and bench.py's roofline prices) includes it
+  uint32_t *rank_pending = nullptr;
+  int launch_rank(const Params &, uint32_t *perm) {
+    rank_pending = perm;
     return SF_OK;
   }
   int launch_step(const Params &p, int NB, const uint8_t *cmds, int k) {
     SF_HIP(hipSetDevice(device));
+    if (large_pools(p.Z, p.P)) return do_step<4, true>(p, cmds, k);
     switch (NB) {
-      case 1: return do_step<1>(p, cmds, k);
-      case 2: return do_step<2>(p, cmds, k);
-      case 3: return do_step<3>(p, cmds, k);
-      default: return do_step<4>(p, cmds, k);
+      case 1: return do_step<1, false>(p, cmds, k);
+      case 2: return do_step<2, false>(p, cmds, k);
+      case 3: return do_step<3, false>(p, cmds, k);
+      default: return do_step<4, false>(p, cmds, k);
     }
   }
-  template <int NB>
+  template <int NB, bool ZL>
   int do_step_half(const Params &p, const uint8_t *cmds, int phase) {
     const bool hp = hbm_plane(p.cells_pad), bm = use_bitmaps(p.cells_pad);
-    const size_t lds = lds_bytes_for(p.cells_pad, p.lds_tab);
+    const size_t lds = lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P);
+    int rc;
     if (!hp) {
-      int rc = lds_attr(k_step_half<NB, false, true>, lds);
-      if (rc) return rc;
-      hipLaunchKernelGGL((k_step_half<NB, false, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, phase);
+      if ((rc = lds_attr(k_step_half<NB, false, true, ZL>, lds))) return rc;
+      hipLaunchKernelGGL((k_step_half<NB, false, true, ZL>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, phase);
     } else if (bm) {
-      hipLaunchKernelGGL((k_step_half<NB, true, true>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, phase);
+      if ((rc = lds_attr(k_step_half<NB, true, true, ZL>, lds))) return rc;
+      hipLaunchKernelGGL((k_step_half<NB, true, true, ZL>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, phase);
     } else {
-      hipLaunchKernelGGL((k_step_half<NB, true, false>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, phase);
+      if ((rc = lds_attr(k_step_half<NB, true, false, ZL>, lds))) return rc;
+      hipLaunchKernelGGL((k_step_half<NB, true, false, ZL>), dim3((unsigned)p.A), dim3(64), lds, stream, p, cmds, phase);
     }
     SF_HIP(hipGetLastError());
     return SF_OK;
   }
   int launch_step_half(const Params &p, int NB, const uint8_t *cmds, int phase) {
     SF_HIP(hipSetDevice(device));
+    if (large_pools(p.Z, p.P)) return do_step_half<4, true>(p, cmds, phase);
     switch (NB) {
-      case 1: return do_step_half<1>(p, cmds, phase);
-      case 2: return do_step_half<2>(p, cmds, phase);
-      case 3: return do_step_half<3>(p, cmds, phase);
-      default: return do_step_half<4>(p, cmds, phase);
+      case 1: return do_step_half<1, false>(p, cmds, phase);
+      case 2: return do_step_half<2, false>(p, cmds, phase);
+      case 3: return do_step_half<3, false>(p, cmds, phase);
+      default: return do_step_half<4, false>(p, cmds, phase);
     }
   }
   int launch_agent_alive(const Params &p, uint8_t *d_out) {
@@ -637,8 +661,7 @@ struct HipRT {
   int launch_observe(const Params &p, int, float *out, uint32_t *nzprev, int mode) {
     SF_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(k_observe, dim3((unsigned)(p.A * p.n_agents)), dim3(OBS_THREADS),
-                       (size_t)(HW_WORDS * p.H + ZW_WORDS * p.Z + BW_WORDS * p.B) * sizeof(uint32_t) + sizeof(int32_t) * 12 +
-                           sizeof(Derived) * (size_t)(p.npc_block + 1),
+                       obs_lds_bytes(p),
                        stream, p, out, nzprev, mode, ObsSparse{});
     SF_HIP(hipGetLastError());
     return SF_OK;
@@ -646,8 +669,7 @@ struct HipRT {
   int launch_observe_sparse(const Params &p, uint32_t *keys, float *vals, uint32_t *counts, float *pov, int cap) {
     SF_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(k_observe, dim3((unsigned)(p.A * p.n_agents)), dim3(OBS_THREADS),
-                       (size_t)(HW_WORDS * p.H + ZW_WORDS * p.Z + BW_WORDS * p.B) * sizeof(uint32_t) + sizeof(int32_t) * 12 +
-                           sizeof(Derived) * (size_t)(p.npc_block + 1),
+                       obs_lds_bytes(p),
                        stream, p, (float *)nullptr, (uint32_t *)nullptr, 3, ObsSparse{keys, vals, counts, pov, cap});
     SF_HIP(hipGetLastError());
     return SF_OK;
@@ -657,8 +679,7 @@ struct HipRT {
     SF_HIP(hipSetDevice(device));
     const int n = p.A * p.n_agents;
     hipLaunchKernelGGL(k_observe, dim3((unsigned)n), dim3(OBS_THREADS),
-                       (size_t)(HW_WORDS * p.H + ZW_WORDS * p.Z + BW_WORDS * p.B) * sizeof(uint32_t) + sizeof(int32_t) * 12 +
-                           sizeof(Derived) * (size_t)(p.npc_block + 1),
+                       obs_lds_bytes(p),
                        stream, p, dense, (uint32_t *)nullptr, 4,
                        ObsSparse{nullptr, nullptr, const_cast<uint32_t *>(counts), nullptr, cap});
     SF_HIP(hipGetLastError());
@@ -919,6 +940,7 @@ int sf_results_allgather(sf_env *env, int32_t *d_out) {
   if (!c.comm) return sf::fail(SF_ERR_ARG, "sf_comm_init has not been called");
   if (!d_out) return sf::fail(SF_ERR_ARG, "null gather buffer");
   if (!env->e.was_reset) return sf::fail(SF_ERR_ARG, "sf_reset has not been called");
+  if (int rc0 = env->e.not_mid_step("sf_results_allgather")) return rc0;
   SF_HIP(hipSetDevice(env->e.rt.device));
   hipStream_t st = env->e.rt.stream;
   const size_t count = (size_t)env->e.p.A * env->e.p.n_agents * 8;

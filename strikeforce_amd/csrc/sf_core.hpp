@@ -19,6 +19,10 @@
 #include "../../include/strikeforce.h"
 #include "sf_types.hpp"
 
+#if defined(SF_EXP_FAKE_DRAWS) && !defined(SF_EXPERIMENT_BUILD)
+#error "SF_EXP_FAKE_DRAWS makes draw() return wrong numbers on purpose (tools/experiments/r03_rows): timing builds only, together with -DSF_EXPERIMENT_BUILD"
+#endif
+
 namespace sf {
 
 enum { SH_WALL, SH_HUMAN, SH_ZOMBIE, SH_PUP, SH_PDN, SH_BULLET, SH_CHEST, SH_POUT, SH_EMPTY };
@@ -28,7 +32,13 @@ enum { LIM_PORTAL = 1000, LIM_BLOCK = 1100 };  // G:37
 // `lds` then points at the plane in HBM itself (L2-cached; the same accessors compile to global loads/stores) and
 // only the 2 KiB power table sits in LDS.
 // BITMAPS: the per-cell scratch bitmaps ("cell bitmaps" below) fit in LDS; without them the ballot loops run.
-template <class W, int NB, bool HBM_PLANE = false, bool BITMAPS = !HBM_PLANE>
+// ZL: large slot pools — more than 64 zombie slots or more than 64 portal exits (the reference's pools hold 9000 each,
+// G:37,51-53, and nothing culls the herd: a Timer game on the shipped maps passes 64 live zombies after 1 650 steps and
+// 64 exits, one per NPC human that ever placed its portal, after 6 000).  The zombie table and the exit table then live
+// in LDS, [field][slot], and every phase that sweeps them walks 64-slot words — word-major = slot order — up to the
+// highest word in use (Arena::zwn, pwn).  The register form (one lane per slot) is untouched by it: every ZL branch
+// below is `if constexpr`.
+template <class W, int NB, bool HBM_PLANE = false, bool BITMAPS = !HBM_PLANE, bool ZL = false>
 struct Core {
   using V = typename W::V;
   using P = typename W::P;
@@ -36,8 +46,15 @@ struct Core {
   struct Arena {
     // humans (lane < H)
     V hpos, hfl, hhp, hst, hmd, hk, hdm, hef, hc01, hc23, ht01, ht23, hbpk, hcmd;
-    // zombies (lane < Z)
+    // zombies (lane < Z); with ZL: unused, the table is in LDS at zl[field * zcap + slot]
     V zpos, zhp, zmd;
+    uint32_t *zl;
+    uint32_t zcap;  // slots per field in LDS: 64 * Params::ZW
+    uint32_t zwn;   // words in use: every live zombie's slot is below 64 * zwn; LDS words from zwn on are undefined
+    uint32_t zwhi;  // the largest zwn since load(): HBM words in [zwn, zwhi) still hold an earlier episode's zombies
+    // portal exits with ZL: pl[slot] in LDS behind the zombie table, the same bookkeeping
+    uint32_t *pl;
+    uint32_t pwn, pwhi;
     // bullets (slot = j * 64 + lane)
     V ba[NB], bd[NB], bb[NB], bc[NB];
     // portals (lane < P)
@@ -243,7 +260,32 @@ struct Core {
     uint64_t m = W::ballot(((S.hfl & HF_ALIVE) != 0u) & (S.hpos == q));
     return m ? W::ctz64(m) : -1;
   }
+  // ---- the zombie table: one lane per slot in registers, or (ZL) [field][slot] in LDS ------------------------------
+  // word j = slots 64 j .. 64 j + 63, one per lane
+  static SF_DEV V zl_get(const Arena &S, int f, uint32_t j) { return W::lds_u32(S.zl + (uint32_t)f * S.zcap + 64u * j, W::lane(), W::all()); }
+  static SF_DEV void zl_put(Arena &S, int f, uint32_t j, const V &v, P pred) {
+    W::lds_store_u32(S.zl + (uint32_t)f * S.zcap + 64u * j, W::lane(), v, pred);
+  }
+  // field f of slot i, wave-uniform
+  static SF_DEV uint32_t z_read(const Arena &S, int f, uint32_t i) {
+    if constexpr (ZL) return W::ulds_u32(S.zl + (uint32_t)f * S.zcap, i);
+    return W::readlane(f == ZW_POS ? S.zpos : f == ZW_HP ? S.zhp : S.zmd, i);
+  }
+  static SF_DEV void z_write(Arena &S, int f, uint32_t i, uint32_t v) {
+    if constexpr (ZL) {
+      W::ulds_store_u32(S.zl + (uint32_t)f * S.zcap, i, v);
+    } else {
+      W::setlane(f == ZW_POS ? S.zpos : f == ZW_HP ? S.zhp : S.zmd, i, v);
+    }
+  }
   static SF_DEV int zombie_at(const Arena &S, uint32_t q) {
+    if constexpr (ZL) {
+      for (uint32_t j = 0; j < S.zwn; ++j) {
+        const uint64_t m = W::ballot((zl_get(S, ZW_POS, j) & (ZF_ALIVE | POS_MASK)) == (ZF_ALIVE | q));
+        if (m) return (int)(64u * j) + W::ctz64(m);
+      }
+      return -1;
+    }
     uint64_t m = W::ballot((S.zpos & (ZF_ALIVE | POS_MASK)) == (ZF_ALIVE | q));
     return m ? W::ctz64(m) : -1;
   }
@@ -292,14 +334,58 @@ struct Core {
     return -1;
   }
   static SF_DEV int z_ind(const Arena &S, const Params &p) {
+    if constexpr (ZL) {
+      for (uint32_t j = 0; j < S.zwn; ++j) {
+        const uint64_t fr = ~W::ballot((zl_get(S, ZW_POS, j) & ZF_ALIVE) != 0u) & capmask(p.Z - (int)(64u * j));
+        if (fr) return (int)(64u * j) + W::ctz64(fr);
+      }
+      return S.zwn < (uint32_t)zw_for(p.Z) ? (int)(64u * S.zwn) : -1;  // the first slot of a word not in use yet (z_take opens it)
+    }
     uint64_t fr = ~W::ballot((S.zpos & ZF_ALIVE) != 0u) & capmask(p.Z);
     return fr ? W::ctz64(fr) : -1;
+  }
+  // ---- the exit table: one lane per exit in registers, or (ZL) pl[slot] in LDS ------------------------------------
+  static SF_DEV V pl_get(const Arena &S, uint32_t j) { return W::lds_u32(S.pl + 64u * j, W::lane(), W::all()); }
+  static SF_DEV uint32_t p_read(const Arena &S, uint32_t i) {
+    if constexpr (ZL) return (i >> 6) < S.pwn ? W::ulds_u32(S.pl, i) : 0u;  // (an exit number the map never defined: inactive)
+    return W::readlane(S.ppos, i);
+  }
+  static SF_DEV void p_write(Arena &S, uint32_t i, uint32_t v) {
+    if constexpr (ZL) {
+      if ((i >> 6) >= S.pwn) {  // a word not in use yet is opened with every exit inactive
+        W::lds_store_u32(S.pl + 64u * S.pwn, W::lane(), V(0u), W::all());
+        ++S.pwn;
+        if (S.pwhi < S.pwn) S.pwhi = S.pwn;
+      }
+      W::ulds_store_u32(S.pl, i, v);
+    } else {
+      W::setlane(S.ppos, i, v);
+    }
+  }
+  // ZL: slot i is about to be filled; a word that was not in use is opened with every slot dead
+  static SF_DEV void z_take(Arena &S, uint32_t i) {
+    if constexpr (ZL) {
+      if ((i >> 6) >= S.zwn) {
+        zl_put(S, ZW_POS, S.zwn, V(0u), W::all());
+        zl_put(S, ZW_HP, S.zwn, V(0u), W::all());
+        zl_put(S, ZW_MINDAMAGE, S.zwn, V(0u), W::all());
+        ++S.zwn;
+        if (S.zwhi < S.zwn) S.zwhi = S.zwn;
+      }
+    }
   }
   static SF_DEV int h_ind(const Arena &S, const Params &p) {  // skips `ind` and remote slots
     uint64_t fr = ~W::ballot((S.hfl & (HF_ALIVE | HF_REMOTE)) != 0u) & capmask(p.H) & ~(1ull << p.ind);
     return fr ? W::ctz64(fr) : -1;
   }
   static SF_DEV int p_ind(const Arena &S, const Params &p) {
+    if constexpr (ZL) {
+      for (uint32_t j = 0; j < S.pwn; ++j) {
+        const uint64_t fr = ~W::ballot((pl_get(S, j) & PF_ACTIVE) != 0u) & capmask(p.P - (int)(64u * j));
+        if (fr) return (int)(64u * j) + W::ctz64(fr);
+      }
+      return S.pwn < (uint32_t)zw_for(p.P) ? (int)(64u * S.pwn) : -1;  // (p_write opens the word)
+    }
     uint64_t fr = ~W::ballot((S.ppos & PF_ACTIVE) != 0u) & capmask(p.P);
     return fr ? W::ctz64(fr) : -1;
   }
@@ -418,9 +504,10 @@ struct Core {
         ++S.chests;
       } else {  // `super = (rand() % 4 == 0)`, Zombie::gen_npc CH:850-857
         const uint32_t super_ = d4 == 0u ? 1u : 0u;
-        W::setlane(S.zpos, (uint32_t)index, q | ZF_ALIVE | (super_ ? ZF_SUPER : 0u));
-        W::setlane(S.zhp, (uint32_t)index, (super_ + 1u) * 400u);
-        W::setlane(S.zmd, (uint32_t)index, (super_ + 1u) * 100u);
+        z_take(S, (uint32_t)index);
+        z_write(S, ZW_POS, (uint32_t)index, q | ZF_ALIVE | (super_ ? ZF_SUPER : 0u));
+        z_write(S, ZW_HP, (uint32_t)index, (super_ + 1u) * 400u);
+        z_write(S, ZW_MINDAMAGE, (uint32_t)index, (super_ + 1u) * 100u);
       }
     }
   }
@@ -433,6 +520,10 @@ struct Core {
   // so everything except "is another zombie there now" is computed once, lane-parallel, one lane per zombie, and
   // the slot-ordered loop that fixes the RNG draw order only tests bits, draws, and asks one ballot per move.
   static SF_DEV void zombie_action(Arena &S, uint8_t *lds, const Params &p) {
+    if constexpr (ZL) {
+      zombie_action_zl(S, lds, p);
+      return;
+    }
     SF_PROF(PH_ZOMBIE);
     const P zalive = ((S.zpos & ZF_ALIVE) != 0u) & W::ltu(W::lane(), (uint32_t)p.Z);
     uint64_t zm = W::ballot(zalive);
@@ -552,9 +643,130 @@ struct Core {
     }
   }
 
+
+  // The same phase over a zombie table in LDS (ZL), one 64-slot word after the other.  Within a word the scheme above
+  // applies unchanged (punches first, then the draw loop); between words the reference's slot order is kept as it is.
+  // That the words may be evaluated one after the other against the state as it is then — instead of everything against
+  // the phase's start — follows from the same facts: humans and flags do not change; a punch lands on a human cell,
+  // which is no zombie's own cell and no mover's target (a zombie next to a human punches), so neither `skip` nor a
+  // mover's choice can see it; only "is another zombie there now" depends on earlier zombies, and it is asked at the
+  // zombie's turn, against the table itself.  The humans' and designated bullets' bitmaps are therefore built once, as of
+  // the phase's start, and serve every word.
+  static SF_DEV void zombie_action_zl(Arena &S, uint8_t *lds, const Params &p) {
+    SF_PROF(PH_ZOMBIE);
+    if (!S.zwn) return;
+    const P hocc = (S.hfl & HF_OCC) != 0u;
+    const V hci = cell_index_v(p, S.hpos);
+    if (BITMAPS) {
+      bm_set(S, p, BM_HUM, hci, hocc);
+      bm_bullets(S, p, BM_REF, true);
+    }
+    for (uint32_t j = 0; j < S.zwn; ++j) {
+      const V zpw = zl_get(S, ZW_POS, j);
+      const P zalive = (zpw & ZF_ALIVE) != 0u;
+      const uint64_t zm = W::ballot(zalive);
+      if (!zm) continue;
+      const V zq = zpw & POS_MASK;
+      const V zr = (zq >> 10) & 1023u, zc = zq & 1023u;
+      V freebits = V(0u), hnear = V(0u);
+      const V ci0 = ((zq >> 20) * (uint32_t)p.N + zr) * (uint32_t)p.M + zc;
+      const V qn0 = zq + 1024u, qn1 = zq + 1u, qn2 = zq - 1024u, qn3 = zq - 1u;
+      uint64_t skip = 0ull;
+      V nfl[4];
+      P ninb[4];
+      for (int d = 0; d < 4; ++d) {
+        const V rr = zr + (uint32_t)DX(d), cc = zc + (uint32_t)DY(d);
+        ninb[d] = zalive & W::ltu(rr, (uint32_t)p.N) & W::ltu(cc, (uint32_t)p.M);
+        nfl[d] = W::lds_u8_any(lds, W::select(ninb[d], ci0 + (uint32_t)(DX(d) * p.M + DY(d)), W::select(zalive, ci0, V(0u))));
+      }
+      if (BITMAPS) {
+        skip = W::ballot(zalive & bm_test(S, p, BM_REF, ci0, zalive));
+        for (int d = 0; d < 4; ++d) {
+          const P inb = ninb[d];
+          const V ci = ci0 + (uint32_t)(DX(d) * p.M + DY(d));
+          const P clear = inb & (nfl[d] == 0u) & (!bm_test(S, p, BM_REF, ci, inb));
+          freebits = freebits | W::select(clear, V(1u << d), V(0u));
+          hnear = hnear | W::select(inb & bm_test(S, p, BM_HUM, ci, inb), V(1u << d), V(0u));
+        }
+      } else {
+        for (int d = 0; d < 4; ++d) freebits = freebits | W::select(ninb[d] & (nfl[d] == 0u), V(1u << d), V(0u));
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+          uint64_t bm = W::ballot((S.ba[jb] & BA_REF) != 0u);
+          while (bm) {
+            const uint32_t l = (uint32_t)W::ctz64(bm);
+            bm &= bm - 1ull;
+            const uint32_t q = W::readlane(S.ba[jb], l) & POS_MASK;
+            skip |= W::ballot(zalive & (zq == q));
+            const V hit = W::select(qn0 == q, V(1u), V(0u)) | W::select(qn1 == q, V(2u), V(0u)) |
+                          W::select(qn2 == q, V(4u), V(0u)) | W::select(qn3 == q, V(8u), V(0u));
+            freebits = freebits & ~hit;
+          }
+        }
+        uint64_t hm = W::ballot(hocc);
+        while (hm) {
+          const uint32_t h = (uint32_t)W::ctz64(hm);
+          hm &= hm - 1ull;
+          const uint32_t q = W::readlane(S.hpos, h);
+          hnear = hnear | W::select(zalive & ((qn0 == q) | (qn1 == q) | (qn2 == q) | (qn3 == q)), V(15u), V(0u));
+        }
+      }
+      const uint64_t todo = zm & ~skip;
+      uint64_t nearm = W::ballot(hnear != 0u) & todo;
+      uint64_t falls = 0ull;
+      while (nearm) {
+        const uint32_t z = (uint32_t)W::ctz64(nearm);
+        const uint64_t bit = nearm & (0ull - nearm);
+        nearm ^= bit;
+        const uint32_t q0 = W::readlane(zq, z);
+        const int f = pos_f(q0), r = pos_r(q0), c = pos_c(q0);
+        const int zmd = (int)z_read(S, ZW_MINDAMAGE, 64u * j + z);
+        const uint32_t hn = W::readlane(hnear, z);
+        bool b = false;
+        for (int i1 = 0; i1 < 4; ++i1) {
+          if (!((hn >> i1) & 1u)) continue;
+          const int rr = r + DX(i1), cc = c + DY(i1);
+          if (!inmap(p, rr, cc)) continue;
+          const uint32_t q = pos_pack(f, rr, cc);
+          if (BITMAPS || human_at(S, q) >= 0) {
+            int index = b_ind(S, p);
+            if (refbullet_at(S, q) < 0 && index != -1) bullet_put(S, index, q, i1 + 1, zmd > 0 ? zmd : 0, 0, 1, 0);
+            b = true;
+          }
+        }
+        if (!b) falls |= bit;
+      }
+      uint64_t movers = (todo & ~W::ballot(hnear != 0u)) | falls;
+      while (movers) {
+        const uint32_t z = (uint32_t)W::ctz64(movers);
+        movers &= movers - 1ull;
+        if (mod5(draw(S, lds, p)) < 2u) continue;
+        const uint32_t fb = W::readlane(freebits, z);
+        const uint32_t zp = W::readlane(zpw, z);  // (its own entry of the table: nobody else has written it)
+        SF_NOUNROLL for (int i1 = 0; i1 < 2; ++i1) {
+          const uint32_t i2 = draw(S, lds, p) & 3u;
+          if (!((fb >> i2) & 1u)) continue;
+          const uint32_t q = (zp & POS_MASK) + (uint32_t)(int32_t)(int16_t)(0xFFFFFC0000010400ull >> (i2 * 16u));
+          if (zombie_at(S, q) >= 0) continue;  // the table as it is now: earlier zombies have moved
+          z_write(S, ZW_POS, 64u * j + z, (zp & ~POS_MASK) | q);
+          break;
+        }
+      }
+    }
+    if (BITMAPS) {
+      bm_clear(S, p, BM_HUM, hci, hocc);
+      // (the punches above have designated new bullets and orphaned old ones: the whole bitmap, not the present bullets' words)
+      W::lds_zero(S.bm + BM_REF * p.bm_words, (uint32_t)p.bm_words);
+    }
+  }
+
   // ------------------------------------------------------------------------------------------------
   // portal_damage G:1279-1297
   static SF_DEV void portal_damage(Arena &S, uint8_t *lds, const Params &p) {
+    if constexpr (ZL) {
+      portal_damage_zl(S, lds, p);
+      return;
+    }
     SF_PROF(PH_PORTAL);
     const uint64_t pm = W::ballot((S.ppos & PF_ACTIVE) != 0u) & capmask(p.P);
     if (!pm) return;
@@ -573,11 +785,11 @@ struct Core {
       const P hocc = (S.hfl & HF_OCC) != 0u, zlive = (S.zpos & ZF_ALIVE) != 0u;
       const V hci = cell_index_v(p, S.hpos), zci = cell_index_v(p, S.zpos);
       bm_set(S, p, BM_HUM, hci, hocc);
-      bm_set(S, p, BM_ZOM, zci, zlive);
+      if constexpr (ZL) bm_zombies_zl(S, p, BM_ZOM, true); else bm_set(S, p, BM_ZOM, zci, zlive);
       bm_bullets(S, p, BM_REF, true);
       const P covered = bm_test(S, p, BM_HUM, pci, plain) | bm_test(S, p, BM_ZOM, pci, plain) | bm_test(S, p, BM_REF, pci, plain);
       bm_clear(S, p, BM_HUM, hci, hocc);
-      bm_clear(S, p, BM_ZOM, zci, zlive);
+      if constexpr (ZL) bm_zombies_zl(S, p, BM_ZOM, false); else bm_clear(S, p, BM_ZOM, zci, zlive);
       bm_bullets(S, p, BM_REF, false);
       need = pm & ~W::ballot(plain & (!covered));
     } else {
@@ -598,6 +810,62 @@ struct Core {
     }
   }
 
+
+  // The same phase over an exit table in LDS (ZL), word by word in slot order.  Whether an exit is covered does not
+  // depend on the radiation bullets of earlier exits (they land on those exits' own cells), so each word is evaluated
+  // when its turn comes; the occupancy bitmaps are built once, at the first word that has a plain exit.
+  static SF_DEV void portal_damage_zl(Arena &S, uint8_t *lds, const Params &p) {
+    SF_PROF(PH_PORTAL);
+    const P hocc = (S.hfl & HF_OCC) != 0u;
+    const V hci = cell_index_v(p, S.hpos);
+    bool built = false, dry = false;
+    for (uint32_t j = 0; j < S.pwn && !dry; ++j) {
+      const V ppw = pl_get(S, j);
+      const P act = (ppw & PF_ACTIVE) != 0u;
+      const uint64_t pm = W::ballot(act);
+      if (!pm) continue;
+      const V pci = cell_index_v(p, ppw);
+      const V fl = W::lds_u8(lds, pci, act);
+      const P plain = act & ((fl & (uint32_t)(SF_CELL_WALL | SF_CELL_PIN_UP | SF_CELL_PIN_DN | SF_CELL_CHEST | SF_CELL_POUT)) ==
+                             (uint32_t)SF_CELL_POUT);
+      uint64_t need = pm;
+      uint64_t plm = W::ballot(plain);
+      if (BITMAPS && plm) {
+        if (!built) {
+          bm_set(S, p, BM_HUM, hci, hocc);
+          bm_zombies_zl(S, p, BM_ZOM, true);
+          bm_bullets(S, p, BM_REF, true);
+          built = true;
+        }
+        const P covered = bm_test(S, p, BM_HUM, pci, plain) | bm_test(S, p, BM_ZOM, pci, plain) | bm_test(S, p, BM_REF, pci, plain);
+        need = pm & ~W::ballot(plain & (!covered));
+      } else {
+        while (plm) {
+          const uint32_t i = (uint32_t)W::ctz64(plm);
+          const uint64_t bit = plm & (0ull - plm);
+          plm ^= bit;
+          const uint32_t q = W::readlane(ppw, i) & POS_MASK;
+          if (human_at(S, q) < 0 && zombie_at(S, q) < 0 && refbullet_at(S, q) < 0) need &= ~bit;
+        }
+      }
+      while (need) {
+        const uint32_t i = (uint32_t)W::ctz64(need);
+        need &= need - 1ull;
+        int index = b_ind(S, p);
+        if (index == -1) {  // `return;` G:1289
+          dry = true;
+          break;
+        }
+        bullet_put(S, index, W::readlane(ppw, i) & POS_MASK, 3, 20, -10, 1, 0);
+      }
+    }
+    if (built) {
+      bm_clear(S, p, BM_HUM, hci, hocc);
+      bm_zombies_zl(S, p, BM_ZOM, false);
+      W::lds_zero(S.bm + BM_REF * p.bm_words, (uint32_t)p.bm_words);  // (the radiation bullets took over their cells' designation)
+    }
+  }
+
   // ------------------------------------------------------------------------------------------------
   // update_tmp G:1343-1381.  Bullets standing on destructible '#' / '^' cells are absorbed; objects whose
   // accumulated damage crossed the limit are removed.  Only a cell that absorbed a bullet in this call can
@@ -611,12 +879,12 @@ struct Core {
     const int32_t d = W::uload_i32(dmg + ci);
     if (sit == SH_PUP && d >= LIM_PORTAL) {
       const int i = (int)W::uload_i16(p.aux_pidx + (size_t)a * (size_t)p.cells + ci);
-      const uint32_t e1 = W::readlane(S.ppos, (uint32_t)i) & POS_MASK;
+      const uint32_t e1 = p_read(S, (uint32_t)i) & POS_MASK;
       const uint32_t c1 = cellidx_q(p, e1);
       W::ulds_store_u8(lds, c1, W::ulds_u8(lds, c1) & ~(uint32_t)(SF_CELL_POUT | SF_CELL_TEMP));
       W::ulds_store_u8(lds, ci, fl & ~(uint32_t)(SF_CELL_PIN_UP | SF_CELL_TEMP));
       W::ustore_i32(dmg + ci, 0);
-      W::setlane(S.ppos, (uint32_t)i, 0u);
+      p_write(S, (uint32_t)i, 0u);
       S.dirty = 1u;
     } else if (sit == SH_WALL && d >= LIM_BLOCK) {
       W::ulds_store_u8(lds, ci, fl & ~(uint32_t)(SF_CELL_WALL | SF_CELL_TEMP));
@@ -714,6 +982,18 @@ struct Core {
     }
   }
 
+  static SF_DEV void bm_zombies_zl(Arena &S, const Params &p, int which, bool set) {  // ZL: every live zombie's cell
+    for (uint32_t j = 0; j < S.zwn; ++j) {
+      const V zpw = zl_get(S, ZW_POS, j);
+      const P zlive = (zpw & ZF_ALIVE) != 0u;
+      const V zci = cell_index_v(p, zpw);
+      if (set)
+        bm_set(S, p, which, zci, zlive);
+      else
+        bm_clear(S, p, which, zci, zlive);
+    }
+  }
+
   // ------------------------------------------------------------------------------------------------
   // hit_human + hit_zombie G:574-652.  A cell holds at most one character and a hit consumes only the
   // cell's designated bullet, so the two slot-ordered sweeps reduce to: (1) humans already at Hp <= 0 die
@@ -754,16 +1034,16 @@ struct Core {
         if (cross) add_lane(S.hk, (uint32_t)(owner - 1), 1);
       }
     } else {  // zombie_damage G:574-598
-      const uint32_t zp = W::readlane(S.zpos, (uint32_t)zv);
-      const int32_t hp = (int32_t)W::readlane(S.zhp, (uint32_t)zv) - dmg;
-      W::setlane(S.zhp, (uint32_t)zv, (uint32_t)hp);
-      add_lane(S.zmd, (uint32_t)zv, eff);
+      const uint32_t zp = z_read(S, ZW_POS, (uint32_t)zv);
+      const int32_t hp = (int32_t)z_read(S, ZW_HP, (uint32_t)zv) - dmg;
+      z_write(S, ZW_HP, (uint32_t)zv, (uint32_t)hp);
+      z_write(S, ZW_MINDAMAGE, (uint32_t)zv, z_read(S, ZW_MINDAMAGE, (uint32_t)zv) + (uint32_t)eff);
       if (owner) {
         add_lane(S.hdm, (uint32_t)(owner - 1), dmg);
         add_lane(S.hef, (uint32_t)(owner - 1), eff);
       }
       if (hp <= 0) {
-        W::setlane(S.zpos, (uint32_t)zv, 0u);
+        z_write(S, ZW_POS, (uint32_t)zv, 0u);
         if (owner && owner_team == my_team) {
           const int pts = 500 + ((zp & ZF_SUPER) ? 250 : 0);
           ++S.tkills, S.loot += pts / 10;
@@ -787,6 +1067,31 @@ struct Core {
 #pragma unroll
       for (int j = 0; j < NB; ++j) any = any || W::ballot((S.ba[j] & BA_REF) != 0u) != 0ull;
       if (!any) return;
+      if constexpr (ZL) {
+        // humans first, then the zombies in slot order, word by word.  The bitmap stays as built meanwhile: a hit takes
+        // its cell's bullet, and no second character stands on that cell to test the stale bit
+        bm_bullets(S, p, BM_REF, true);
+        const P hlive = (S.hfl & HF_ALIVE) != 0u;
+        uint64_t hm = W::ballot(bm_test(S, p, BM_REF, cell_index_v(p, S.hpos), hlive) & hlive);
+        while (hm) {
+          const uint32_t i = (uint32_t)W::ctz64(hm);
+          hm &= hm - 1ull;
+          hit_one(S, p, my_team, refbullet_at(S, W::readlane(S.hpos, i)), (int)i, -1);
+        }
+        for (uint32_t j = 0; j < S.zwn; ++j) {
+          const V zpw = zl_get(S, ZW_POS, j);
+          const P zlive = (zpw & ZF_ALIVE) != 0u;
+          uint64_t zmk = W::ballot(bm_test(S, p, BM_REF, cell_index_v(p, zpw), zlive) & zlive);
+          while (zmk) {
+            const uint32_t i = (uint32_t)W::ctz64(zmk);
+            zmk &= zmk - 1ull;
+            const int slot = refbullet_at(S, W::readlane(zpw, i) & POS_MASK);
+            if (slot >= 0) hit_one(S, p, my_team, slot, -1, (int)(64u * j + i));
+          }
+        }
+        W::lds_zero(S.bm + BM_REF * p.bm_words, (uint32_t)p.bm_words);
+        return;
+      }
       {
       bm_bullets(S, p, BM_REF, true);
       const P hlive = (S.hfl & HF_ALIVE) != 0u;
@@ -937,7 +1242,7 @@ struct Core {
     const int index = (fl & SF_CELL_TEMP) ? (int)W::uload_i16(p.aux_pidx + (size_t)a * (size_t)p.cells + ci)
                                           : (int)W::uload_i16(p.map_pidx + ci);
     if (index < 0 || index >= p.P) return;
-    const uint32_t e = W::readlane(S.ppos, (uint32_t)index) & POS_MASK;
+    const uint32_t e = p_read(S, (uint32_t)index) & POS_MASK;
     uint32_t efl;
     if (showit_q(S, lds, p, e, efl) != SH_POUT) return;
     W::setlane(S.hpos, i, e);
@@ -986,7 +1291,7 @@ struct Core {
         W::ulds_store_u8(lds, ci, fl | SF_CELL_TEMP | SF_CELL_POUT);
         W::ustore_i32(dmg + ci, 0);
         W::setlane(S.hbpk, i, (bp - 256u) | ((uint32_t)(index + 1) << 16));
-        W::setlane(S.ppos, (uint32_t)index, pos_pack(f, rr, cc) | PF_ACTIVE);
+        p_write(S, (uint32_t)index, pos_pack(f, rr, cc) | PF_ACTIVE);
         S.dirty = 1u;
       }
       return;
@@ -1202,12 +1507,12 @@ struct Core {
       const V hci = cell_index_v(p, S.hpos), zci = cell_index_v(p, S.zpos);
       const bool bul = W::ballot(needb) != 0ull;
       bm_set(S, p, BM_HUM, hci, hocc);
-      bm_set(S, p, BM_ZOM, zci, zlive);
+      if constexpr (ZL) bm_zombies_zl(S, p, BM_ZOM, true); else bm_set(S, p, BM_ZOM, zci, zlive);
       if (bul) bm_bullets(S, p, BM_REF, true);
       oH = bm_test(S, p, BM_HUM, tci, inb), oZ = bm_test(S, p, BM_ZOM, tci, inb);
       oB = needb & bm_test(S, p, BM_REF, tci, needb);
       bm_clear(S, p, BM_HUM, hci, hocc);
-      bm_clear(S, p, BM_ZOM, zci, zlive);
+      if constexpr (ZL) bm_zombies_zl(S, p, BM_ZOM, false); else bm_clear(S, p, BM_ZOM, zci, zlive);
       if (bul) bm_bullets(S, p, BM_REF, false);
       // (the bitmaps are free again) the cells of humans that may walk away, then the claims of the targets
       bm_set(S, p, BM_HUM, oci, is_move);
@@ -1229,7 +1534,11 @@ struct Core {
         const uint64_t hs = W::ballot(((S.hfl & HF_OCC) != 0u) & (S.hpos == q));
         const uint64_t same = W::ballot(inb & (tq == q));
         if (hs) occH |= bit;
-        if (W::ballot((S.zpos & (ZF_ALIVE | POS_MASK)) == (ZF_ALIVE | q))) occZ |= bit;
+        if constexpr (ZL) {
+          if (zombie_at(S, q) >= 0) occZ |= bit;
+        } else {
+          if (W::ballot((S.zpos & (ZF_ALIVE | POS_MASK)) == (ZF_ALIVE | q))) occZ |= bit;
+        }
         if ((needbm & bit) && refbullet_at(S, q) >= 0) occB |= bit;
         // the human standing there may move away in this sweep; another human aims at the same cell
         if ((hs & movers) || (same & (same - 1ull))) slow = true;
@@ -1431,9 +1740,20 @@ struct Core {
     S.hef = V(0u), S.hc01 = V(0u), S.hc23 = V(0u), S.ht01 = V(0u), S.ht23 = V(0u), S.hbpk = V(0u);
     S.hcmd = V((uint32_t)'+');
     S.zpos = V(0u), S.zhp = V(0u), S.zmd = V(0u);
+    if constexpr (ZL) S.zwn = 0u;  // (store() clears the words the episode before had in use, zwhi)
 #pragma unroll
     for (int j = 0; j < NB; ++j) S.ba[j] = V(0u), S.bd[j] = V(0u), S.bb[j] = V(0u), S.bc[j] = V(0u);
-    S.ppos = W::gload(p.map_exits, W::lane(), W::ltu(W::lane(), (uint32_t)p.P));
+    if constexpr (ZL) {
+      S.ppos = V(0u);
+      S.pwn = (uint32_t)p.pw0;  // the map's own exits fill the first words
+      for (uint32_t j = 0; j < S.pwn; ++j) {
+        const V sl = W::lane() + 64u * j;
+        W::lds_store_u32(S.pl + 64u * j, W::lane(), W::gload(p.map_exits, sl, W::ltu(sl, (uint32_t)p.P)), W::all());
+      }
+      if (S.pwhi < S.pwn) S.pwhi = S.pwn;
+    } else {
+      S.ppos = W::gload(p.map_exits, W::lane(), W::ltu(W::lane(), (uint32_t)p.P));
+    }
     W::copy_g2l(lds, p.map_flags, (uint32_t)p.cells_pad);
     S.dirty = 1u;
     if (adopt) {
@@ -1550,7 +1870,20 @@ struct Core {
       S.hbpk = W::gload(h + HW_BPK * AH, ln, in);
       S.hcmd = V((uint32_t)'+');
     }
-    {
+    if constexpr (ZL) {
+      S.zpos = V(0u), S.zhp = V(0u), S.zmd = V(0u);
+      const uint32_t *z = p.zom + (size_t)a * (size_t)p.Z;
+      S.zwn = (uint32_t)W::uload_i32(p.scal + (size_t)a * SC_WORDS + SC_ZWN);
+      if (S.zwn > (uint32_t)zw_for(p.Z)) S.zwn = (uint32_t)zw_for(p.Z);
+      S.zwhi = S.zwn;
+      for (uint32_t j = 0; j < S.zwn; ++j) {
+        const V sl = ln + 64u * j;
+        const P in = W::ltu(sl, (uint32_t)p.Z);
+        zl_put(S, ZW_POS, j, W::gload(z + ZW_POS * AZ, sl, in), W::all());
+        zl_put(S, ZW_HP, j, W::gload(z + ZW_HP * AZ, sl, in), W::all());
+        zl_put(S, ZW_MINDAMAGE, j, W::gload(z + ZW_MINDAMAGE * AZ, sl, in), W::all());
+      }
+    } else {
       const P in = W::ltu(ln, (uint32_t)p.Z);
       const uint32_t *z = p.zom + (size_t)a * (size_t)p.Z;
       S.zpos = W::gload(z + ZW_POS * AZ, ln, in), S.zhp = W::gload(z + ZW_HP * AZ, ln, in);
@@ -1564,7 +1897,18 @@ struct Core {
       S.ba[j] = W::gload(b + BW_A * AB, sl, in), S.bd[j] = W::gload(b + BW_DAMAGE * AB, sl, in);
       S.bb[j] = W::gload(b + BW_B * AB, sl, in), S.bc[j] = W::gload(b + BW_C * AB, sl, in);
     }
-    S.ppos = W::gload(p.por + (size_t)a * (size_t)p.P, ln, W::ltu(ln, (uint32_t)p.P));
+    if constexpr (ZL) {
+      S.ppos = V(0u);
+      S.pwn = (uint32_t)W::uload_i32(p.scal + (size_t)a * SC_WORDS + SC_PWN);
+      if (S.pwn > (uint32_t)zw_for(p.P)) S.pwn = (uint32_t)zw_for(p.P);
+      S.pwhi = S.pwn;
+      for (uint32_t j = 0; j < S.pwn; ++j) {
+        const V sl = ln + 64u * j;
+        W::lds_store_u32(S.pl + 64u * j, ln, W::gload(p.por + (size_t)a * (size_t)p.P, sl, W::ltu(sl, (uint32_t)p.P)), W::all());
+      }
+    } else {
+      S.ppos = W::gload(p.por + (size_t)a * (size_t)p.P, ln, W::ltu(ln, (uint32_t)p.P));
+    }
     {
       // one dword per tap: random[i] | us[i] << 20 | seed[i] << 24  (RN:31; us/seed are decimal digits + 1)
       const P in = W::ltu(ln, 18u);
@@ -1605,7 +1949,21 @@ struct Core {
       W::gstore(h + HW_THR01 * AH, ln, S.ht01, in), W::gstore(h + HW_THR23 * AH, ln, S.ht23, in);
       W::gstore(h + HW_BPK * AH, ln, S.hbpk, in);
     }
-    {
+    uint32_t zlive_n = 0u;
+    (void)zlive_n;
+    if constexpr (ZL) {
+      uint32_t *z = p.zom + (size_t)a * (size_t)p.Z;
+      for (uint32_t j = 0; j < S.zwhi; ++j) {  // words an earlier episode of this launch had in use are cleared in HBM
+        const V sl = ln + 64u * j;
+        const P in = W::ltu(sl, (uint32_t)p.Z);
+        const bool used = j < S.zwn;
+        const V zpw = used ? zl_get(S, ZW_POS, j) : V(0u);
+        W::gstore(z + ZW_POS * AZ, sl, zpw, in);
+        W::gstore(z + ZW_HP * AZ, sl, used ? zl_get(S, ZW_HP, j) : V(0u), in);
+        W::gstore(z + ZW_MINDAMAGE * AZ, sl, used ? zl_get(S, ZW_MINDAMAGE, j) : V(0u), in);
+        zlive_n += (uint32_t)W::popc64(W::ballot((zpw & ZF_ALIVE) != 0u));
+      }
+    } else {
       const P in = W::ltu(ln, (uint32_t)p.Z);
       uint32_t *z = p.zom + (size_t)a * (size_t)p.Z;
       W::gstore(z + ZW_POS * AZ, ln, S.zpos, in), W::gstore(z + ZW_HP * AZ, ln, S.zhp, in);
@@ -1619,7 +1977,14 @@ struct Core {
       W::gstore(b + BW_A * AB, sl, S.ba[j], in), W::gstore(b + BW_DAMAGE * AB, sl, S.bd[j], in);
       W::gstore(b + BW_B * AB, sl, S.bb[j], in), W::gstore(b + BW_C * AB, sl, S.bc[j], in);
     }
-    W::gstore(p.por + (size_t)a * (size_t)p.P, ln, S.ppos, W::ltu(ln, (uint32_t)p.P));
+    if constexpr (ZL) {
+      for (uint32_t j = 0; j < S.pwhi; ++j) {
+        const V sl = ln + 64u * j;
+        W::gstore(p.por + (size_t)a * (size_t)p.P, sl, j < S.pwn ? pl_get(S, j) : V(0u), W::ltu(sl, (uint32_t)p.P));
+      }
+    } else {
+      W::gstore(p.por + (size_t)a * (size_t)p.P, ln, S.ppos, W::ltu(ln, (uint32_t)p.P));
+    }
     {
       // a stored generator is always warmed up (k_reset runs _srand's 1024 draws), so no tap is zero; bit 16 of the
       // hot state is not a flag (see draw())
@@ -1639,8 +2004,14 @@ struct Core {
     W::setlane(sc, SC_SR_LO, S.sr_lo), W::setlane(sc, SC_SR_HI, S.sr_hi);
     W::setlane(sc, SC_DRAWS, S.jomle - (18u + 1024u));  // _rand() calls since the episode's _srand: jomle counts them
     W::setlane(sc, SC_WARM, S.warm);
-    W::setlane(sc, SC_LOAD, (uint32_t)(W::popc64(W::ballot(((S.zpos & ZF_ALIVE) != 0u) & W::ltu(ln, (uint32_t)p.Z))) +
-                                       W::popc64(W::ballot(((S.hfl & HF_ALIVE) != 0u) & W::ltu(ln, (uint32_t)p.H)))));
+    if constexpr (ZL) {
+      W::setlane(sc, SC_LOAD, zlive_n + (uint32_t)W::popc64(W::ballot(((S.hfl & HF_ALIVE) != 0u) & W::ltu(ln, (uint32_t)p.H))));
+      W::setlane(sc, SC_ZWN, S.zwn);
+      W::setlane(sc, SC_PWN, S.pwn);
+    } else {
+      W::setlane(sc, SC_LOAD, (uint32_t)(W::popc64(W::ballot(((S.zpos & ZF_ALIVE) != 0u) & W::ltu(ln, (uint32_t)p.Z))) +
+                                         W::popc64(W::ballot(((S.hfl & HF_ALIVE) != 0u) & W::ltu(ln, (uint32_t)p.H)))));
+    }
     W::gstore((uint32_t *)p.scal + (size_t)a * SC_WORDS, ln, sc, W::ltu(ln, (uint32_t)SC_WORDS));
     if (!HBM_PLANE && S.dirty) W::copy_l2g(p.flags + (size_t)a * (size_t)p.cells_pad, lds, (uint32_t)p.cells_pad);
   }
@@ -1661,6 +2032,13 @@ struct Core {
       S.bm = reinterpret_cast<uint32_t *>(lds + p.lds_tab + (HBM_PLANE ? 0 : p.cells_pad));
       W::lds_zero(S.bm, (uint32_t)(BM_COUNT * p.bm_words));
     }
+    S.zl = nullptr, S.zcap = 0u, S.zwn = 0u, S.zwhi = 0u;
+    S.pl = nullptr, S.pwn = 0u, S.pwhi = 0u;
+    if constexpr (ZL) {
+      S.zl = reinterpret_cast<uint32_t *>(lds + p.lds_tab + (HBM_PLANE ? 0 : p.cells_pad) + (BITMAPS ? BM_COUNT * 4 * p.bm_words : 0));
+      S.zcap = 64u * (uint32_t)zw_for(p.Z);
+      S.pl = S.zl + ZW_WORDS * S.zcap;
+    }
     S.la = V(0u);
     S.la2 = V(0u), S.la2_ok = 0u;
     return HBM_PLANE ? p.flags + (size_t)a * (size_t)p.cells_pad : lds + p.lds_tab;
@@ -1671,6 +2049,7 @@ struct Core {
     S.episodes = 0, S.ended = 0;
     lds = tables(S, lds, p, a);
     S.rl2 = V(RL_ZERO), S.rseed2 = V(0u), S.warm = 0u, S.wrate = 1u;
+    if constexpr (ZL) S.zwhi = (uint32_t)zw_for(p.Z), S.pwhi = (uint32_t)zw_for(p.P);  // store() writes the whole tables once: slots beyond zwn / pwn are zero in HBM from here on
     reset_state(S, lds, p, tb[a], serial[a], false);
     ++S.frame;  // G:1441
     loop_top(S, lds, p, a);

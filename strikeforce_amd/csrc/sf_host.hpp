@@ -120,9 +120,9 @@ inline int validate(const sf_config *c) {
   if (c->rows < 3 || c->cols < 3 || c->rows > SF_MAX_COORD || c->cols > SF_MAX_COORD)
     return fail(SF_ERR_ARG, "rows/cols must be 3..1024");
   if (c->cap_humans < 1 || c->cap_humans > SF_MAX_HUMANS) return fail(SF_ERR_ARG, "cap_humans must be 1..64");
-  if (c->cap_zombies < 1 || c->cap_zombies > SF_MAX_ZOMBIES) return fail(SF_ERR_ARG, "cap_zombies must be 1..64");
+  if (c->cap_zombies < 1 || c->cap_zombies > SF_MAX_ZOMBIES) return fail(SF_ERR_ARG, "cap_zombies must be 1..9000");
   if (c->cap_bullets < 1 || c->cap_bullets > SF_MAX_BULLETS) return fail(SF_ERR_ARG, "cap_bullets must be 1..256");
-  if (c->cap_portals < 1 || c->cap_portals > SF_MAX_PORTALS) return fail(SF_ERR_ARG, "cap_portals must be 1..64");
+  if (c->cap_portals < 1 || c->cap_portals > SF_MAX_PORTALS) return fail(SF_ERR_ARG, "cap_portals must be 1..9000");
   if (c->cap_chests < 0) return fail(SF_ERR_ARG, "cap_chests < 0");
   if (c->reseed_stride < 0) return fail(SF_ERR_ARG, "reseed_stride < 0");
   if (c->ind < 0 || c->ind >= c->n_agents || (c->ind != 0 && c->mode != SF_MODE_BATTLE))
@@ -194,8 +194,8 @@ struct Env {
   uint32_t *d_exptab = nullptr;
   uint64_t *d_tb = nullptr, *d_serial = nullptr;
   uint8_t *d_cmd = nullptr;
-  uint16_t *d_perm = nullptr;  // k_step's launch order (k_rank): arenas by population; long launches of <= 4096 arenas
-  int balance = -1;            // SF_BALANCE=0 switches the ordering off (A/B measurements)
+  uint32_t *d_perm = nullptr;  // k_step's launch order (k_rank): arenas by population, for long launches
+  int balance = 1;             // SF_BALANCE=0 switches the ordering off, 2 forces it on HBM-plane maps too (A/B measurements)
   int steps_since_rank = 1 << 30;  // the order is renewed every >= 100 steps (populations change by one every 20-25 steps)
   float *d_obs = nullptr;
   uint32_t *d_nzprev = nullptr;      // [A * n_agents][961] which floats of the delta-tracked buffer are non-zero
@@ -234,13 +234,19 @@ struct Env {
     p.timer_lim = cfg.level * (cfg.timer_frames_per_level > 0 ? cfg.timer_frames_per_level : 7500);
     p.squad_floor = cfg.floors > 2 ? 2 : cfg.floors - 1;
     p.ind = cfg.ind;
-    NB = nb_for(p.B);
+    // large pools (zombie / exit tables in LDS): one kernel instance, built for four bullet words (any B up to 256)
+    NB = large_pools(p.Z, p.P) ? 4 : nb_for(p.B);
+    {
+      const char *e = getenv("SF_BALANCE");  // (A/B measurements: SF_BALANCE=0 switches k_rank's launch order off)
+      balance = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
+    }
     // tables: one shared player record (block 0) + npc (block 1), or one record per commanded human (blocks 0..15,
     // the account blobs of a lock-step match, gameplay.hpp:120-151) + npc (block 16)
     p.npc_block = cfg.n_agent_profiles > 0 ? MAX_PROFILE_BLOCKS - 1 : 1;
     p.ht_bytes = ht_bytes_for(p.npc_block + 1), p.lds_tab = lds_tab_for(p.npc_block + 1);
-    if (!hbm_plane(p.cells_pad) && lds_bytes_for(p.cells_pad, p.lds_tab) > rt.max_lds())
-      return fail(SF_ERR_ARG, "map does not fit the LDS flag plane");
+    if (lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P) > rt.max_lds())
+      return fail(SF_ERR_ARG, large_pools(p.Z, p.P) ? "flag plane + zombie / exit tables (16 B per zombie slot, 4 B per exit) do not fit the CU's LDS: lower cap_zombies / cap_portals"
+                                                   : "map does not fit the LDS flag plane");
     for (int i = 0; i < p.npc_block; ++i)
       derive_profile(cfg, (cfg.n_agent_profiles > 0 && i < cfg.n_agent_profiles) ? cfg.agent_profile[i] : cfg.player, tab.der[i]);
     derive_profile(cfg, cfg.npc, tab.der[p.npc_block]);
@@ -306,6 +312,7 @@ struct Env {
         }
       }
     }
+    p.pw0 = zw_for(next_exit);
     cfg.map = nullptr, cfg.map_portal = nullptr;  // the caller's buffers are not kept
     // RNG tables: discrete logs / powers of the generator 3 of Z/65537*
     std::vector<uint16_t> logt(LOGT_ENTRIES, 0);
@@ -377,13 +384,10 @@ struct Env {
     if (!was_reset) return fail(SF_ERR_STATE, "sf_step_device before sf_reset");
     if (mid_step) return fail(SF_ERR_STATE, "sf_step_device between sf_step_begin and sf_step_end");
     // long launches: order the arenas by population first, so that the ones sharing a SIMD are of different loads (k_rank)
-    if (balance < 0) {
-      const char *e = getenv("SF_BALANCE");
-      balance = (e && e[0] == '0') ? 0 : 1;
-    }
     Params q = p;
-    // (maps whose flag plane stays in HBM gained nothing from the order in measurements: left alone)
-    if (balance && k >= 8 && p.A <= 4096 && p.A >= 1024 && rt.can_rank() && !hbm_plane(p.cells_pad)) {
+    // Below 1024 arenas every arena has a SIMD of its own (the chip has 1024): nothing to order.  Maps whose flag plane
+    // stays in HBM gained nothing from the order in measurements (profiles/r04_rank_sweep.txt): left alone.
+    if (balance && k >= 8 && p.A >= 1024 && rt.can_rank() && (!hbm_plane(p.cells_pad) || balance == 2)) {
       int rc;
       if (!d_perm && (rc = alloc(d_perm, (size_t)p.A))) return rc;
       if (steps_since_rank >= 100) {
@@ -471,18 +475,26 @@ struct Env {
     return rt.sync();
   }
 
+  // between sf_step_begin and sf_step_end the episode-end bookkeeping is half done (the first half clears SC_ENDED): only
+  // observe / dump / digest / agent_alive may be called there, as strikeforce.h says
+  int not_mid_step(const char *what) const {
+    return mid_step ? fail(SF_ERR_STATE, std::string(what) + " between sf_step_begin and sf_step_end") : SF_OK;
+  }
   int results_host(int32_t *out) {
     if (!out) return fail(SF_ERR_ARG, "null results buffer");
+    if (int rc = not_mid_step("sf_results")) return rc;
     rt.d2h(out, p.results, (size_t)p.A * p.n_agents * 8 * sizeof(int32_t));
     return rt.sync();
   }
   int results_device(int32_t *d_out) {
     if (!d_out) return fail(SF_ERR_ARG, "null results buffer");
+    if (int rc = not_mid_step("sf_results_device")) return rc;
     rt.d2d(d_out, p.results, (size_t)p.A * p.n_agents * 8 * sizeof(int32_t));
     return SF_OK;
   }
   int done_host(uint8_t *out) {
     if (!out) return fail(SF_ERR_ARG, "null done buffer");
+    if (int rc0 = not_mid_step("sf_done")) return rc0;
     std::vector<int32_t> sc((size_t)p.A * SC_WORDS);
     rt.d2h(sc.data(), p.scal, sc.size() * sizeof(int32_t));
     int rc = rt.sync();
@@ -494,6 +506,7 @@ struct Env {
 
   int done_device(uint8_t *d_out) {
     if (!d_out) return fail(SF_ERR_ARG, "null done buffer");
+    if (int rc = not_mid_step("sf_done_device")) return rc;
     return rt.launch_done(p, d_out);
   }
 

@@ -3,7 +3,7 @@
 // the agent's human is described by 32 channels, channel-major, each mapped by x -> (float)pow(|x|/10, 0.2).
 //
 // The kernel in sf_api.hip stages, per window cell, the flag byte and an occupant word
-// (human+1 | (zombie+1) << 8 | (designated bullet+1) << 16) in LDS and then evaluates obs_value() for
+// (human+1 | (zombie+1) << OCC_Z_SH | (designated bullet+1) << OCC_B_SH) in LDS and then evaluates obs_value() for
 // every one of the 30 752 outputs with coalesced stores.  tests/emu calls the same functions in loops.
 #pragma once
 #include <math.h>
@@ -13,15 +13,24 @@
 
 namespace sf {
 
+// occupant word of a window cell: slots + 1 of the human (<= 64: 7 bits), the zombie (<= 9000: 14 bits) and the
+// designated bullet (<= 256: 9 bits) on it, 0 = none
+constexpr int OCC_Z_SH = 7, OCC_B_SH = 21;
+constexpr uint32_t OCC_H_MASK = 127u, OCC_Z_MASK = 16383u;
+static_assert(SF_MAX_HUMANS <= (int)OCC_H_MASK && SF_MAX_ZOMBIES <= (int)OCC_Z_MASK && SF_MAX_BULLETS + 1 <= (1 << (32 - OCC_B_SH)),
+              "occupant word fields");
+
 struct ObsView {  // read-only view of one arena's entity tables
   const uint32_t *hum_, *zom_, *bul_;
   const Tables *tab;
   int A, H, Z, B, a;
+  int zA, za;     // the zombie table's own arena count / arena (k_observe leaves a large table in HBM beside staged humans and bullets)
   int npc_block;  // Params::npc_block: which table block holds the NPC record
   SF_HD ObsView(const Params &p, int arena)
-      : hum_(p.hum), zom_(p.zom), bul_(p.bul), tab(p.tab), A(p.A), H(p.H), Z(p.Z), B(p.B), a(arena), npc_block(p.npc_block) {}
+      : hum_(p.hum), zom_(p.zom), bul_(p.bul), tab(p.tab), A(p.A), H(p.H), Z(p.Z), B(p.B), a(arena), zA(p.A), za(arena),
+        npc_block(p.npc_block) {}
   SF_HD uint32_t hum(int f, int i) const { return hum_[((size_t)f * A + a) * H + i]; }
-  SF_HD uint32_t zom(int f, int i) const { return zom_[((size_t)f * A + a) * Z + i]; }
+  SF_HD uint32_t zom(int f, int i) const { return zom_[((size_t)f * zA + za) * Z + i]; }
   SF_HD uint32_t bul(int f, int i) const { return bul_[((size_t)f * A + a) * B + i]; }
 };
 
@@ -65,7 +74,7 @@ SF_HD inline void obs_damage_effect(const Derived &d, uint32_t fl, int32_t stami
 // register count low; most cells emit 3 features, most window cells none.)
 template <class F>
 SF_HD inline void obs_cell_emit(const ObsView &v, uint32_t fl, int32_t cdmg, uint32_t occ, int pteam, F &&emit) {
-  const int h = (int)(occ & 255u) - 1, z = (int)((occ >> 8) & 255u) - 1, b = (int)(occ >> 16) - 1;
+  const int h = (int)(occ & OCC_H_MASK) - 1, z = (int)((occ >> OCC_Z_SH) & OCC_Z_MASK) - 1, b = (int)(occ >> OCC_B_SH) - 1;
   const bool s0 = h >= 0, s1 = z >= 0, s2 = b >= 0;
   const bool s3 = fl & SF_CELL_WALL, s4 = fl & SF_CELL_CHEST, s5 = fl & SF_CELL_PIN_UP, s6 = fl & SF_CELL_PIN_DN,
              s7 = fl & SF_CELL_POUT, s10 = fl & SF_CELL_TEMP;

@@ -636,6 +636,7 @@ __global__ __launch_bounds__(B3_T, 1) void k_gemm_b3(Gemm g) {
 constexpr int C0_OUT = 15, C0_ACC = C0_OUT * C0_OUT * HID;  // 36000 floats
 constexpr int C0_T = 1024, C0_WAVES = C0_T / 64;
 constexpr int C0_LCAP = 2048;
+static_assert(C0_LCAP == SF_POLICY_LIST_MAX, "the entry points bound cap by the kernels' list limit");
 constexpr size_t C0_LDS = (size_t)C0_ACC * 4 + (size_t)C0_LCAP * 8 + 4 * (2 * 16 * C0_WAVES + 4);
 
 // LIST: the non-zeros arrive as a list (sf_observe_sparse_device: same keys, same order as the scan below builds), so the
@@ -1883,7 +1884,9 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
           hipLaunchKernelGGL(k_fold, dim3((unsigned)((elems[i] + 255) / 256)), dim3(256), 0, nullptr, T[i + 1], p->conv_w[i], T[i],
                              side[i + 1], side[i], HID, i ? HID : OBS_C, i ? 1 : 0);
         hipLaunchKernelGGL(k_fold_out, dim3((unsigned)(((size_t)OBS_F * HID + 255) / 256)), dim3(256), 0, nullptr, T[0], p->fold);
-        ok = hipDeviceSynchronize() == hipSuccess;
+        // (a launch that never started — a bad configuration — reports here, not at the synchronise: F would stay all zero)
+        ok = hipGetLastError() == hipSuccess;
+        ok = hipDeviceSynchronize() == hipSuccess && ok;
       }
       for (int i = 0; i < 4; ++i)
         if (T[i]) (void)hipFree(T[i]);
@@ -2122,6 +2125,7 @@ int sf_policy_forward_sparse(sf_policy *pp, const uint32_t *d_keys, const float 
   Policy *p = reinterpret_cast<Policy *>(pp);
   if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
   if (!d_keys || !d_vals || !d_counts || !d_pov || cap < 1) return sfp::fail(SF_ERR_ARG, "null buffer or cap < 1");
+  if (cap > SF_POLICY_LIST_MAX) return sfp::fail(SF_ERR_ARG, "cap above SF_POLICY_LIST_MAX (2048)");
   const sfp::C0List li{d_keys, d_vals, d_counts, cap, p->d_overflows};
   return sfp::forward(p, nullptr, agents, d_probs, d_value, &li, d_pov);
 }
@@ -2132,6 +2136,9 @@ int sf_policy_forward_sparse_or_dense(sf_policy *pp, const uint32_t *d_keys, con
   Policy *p = reinterpret_cast<Policy *>(pp);
   if (!p) return sfp::fail(SF_ERR_ARG, "null policy");
   if (!d_keys || !d_vals || !d_counts || !d_pov || !d_dense || cap < 1) return sfp::fail(SF_ERR_ARG, "null buffer or cap < 1");
+  // (above it the kernels' own list limit would call an agent "overflowed" whose dense row sf_observe_overflow_device,
+  // which only knows cap, never wrote)
+  if (cap > SF_POLICY_LIST_MAX) return sfp::fail(SF_ERR_ARG, "cap above SF_POLICY_LIST_MAX (2048)");
   const sfp::C0List li{d_keys, d_vals, d_counts, cap, nullptr};
   return sfp::forward(p, d_dense, agents, d_probs, d_value, &li, d_pov);
 }

@@ -61,6 +61,8 @@ constexpr uint32_t PF_ACTIVE = 1u << 31;
 enum { SC_FRAME = 0, SC_KILLS, SC_TKILLS, SC_LOOT, SC_CHESTS, SC_JOMLE, SC_STEPS, SC_EPISODES, SC_DONE, SC_OUTCOME,
        SC_ENDED, SC_TB_LO, SC_TB_HI, SC_SR_LO, SC_SR_HI, SC_DRAWS, SC_WARM,
        SC_LOAD /* live zombies + live humans when the state was stored: k_rank's key, not part of the game state */,
+       SC_ZWN /* large slot pools (sf_core.hpp ZL): 64-slot words of the zombie table in use */,
+       SC_PWN /* ... and of the exit table */,
        SC_WORDS = 24 };
 constexpr int RNG_WORDS = 18;
 
@@ -110,6 +112,9 @@ struct Params {
   int32_t npc_block;  // table block of the NPC record: 1 (one shared player record in block 0) or 16 (one per agent)
   int32_t ht_bytes;   // used bytes of Tables::hatab
   int32_t lds_tab;    // bytes of [exptab][hatab] at the start of LDS: the flag plane follows
+  int32_t pw0;        // large pools (sf_core.hpp ZL): 64-slot words of the exit table that the map's own exits fill.  (In the
+                      // four bytes that padded `tab` to its alignment: the struct, and with it every kernel's argument
+                      // offsets and register allocation, stays as it was before the large pools existed)
   const Tables *tab;
   uint32_t *hum;   // [HW_WORDS][A][H]
   uint32_t *zom;   // [ZW_WORDS][A][Z]
@@ -131,7 +136,7 @@ struct Params {
   // k_step only: workgroup i steps arena perm[i] (null: arena i).  Arenas are independent, so the order changes nothing
   // but which arenas share a SIMD: k_rank orders them by population, busiest first, so that every SIMD gets one arena
   // of each load quartile instead of whatever the arena numbers bring together (sf_api.hip)
-  const uint16_t *perm;
+  const uint32_t *perm;
 };
 
 // The log table is indexed by the half-reduced tap sum t = lo16(x) - hi16(x), x < 2^25, i.e. t in (-512, 65536):
@@ -149,13 +154,23 @@ inline bool use_bitmaps(int cells_pad) { return BM_COUNT * 4 * bm_words_for(cell
 inline int bm_words_for(int cells) { return ((cells + 31) / 32 + 3) & ~3; }  // words per bitmap, 16-byte multiple
 
 inline int nb_for(int B) { return (B + 63) / 64; }
+// Zombie or exit pools of more than 64 slots (the reference's hold 9000, gameplay.hpp:37,51-53) live in LDS instead of
+// one register lane per slot (Core<.., ZL>): [ZW_WORDS][64 * zombie words] + [64 * exit words] dwords behind the bitmaps
+inline bool large_pools(int Z, int P) { return Z > 64 || P > 64; }
+SF_HD inline int zw_for(int n) { return (n + 63) / 64; }  // 64-slot words of a table of n slots
+inline size_t zl_bytes_for(int Z, int P) {
+  return large_pools(Z, P) ? 4u * 64u * ((size_t)ZW_WORDS * (size_t)zw_for(Z) + (size_t)zw_for(P)) : 0u;
+}
 constexpr int LDS_EXP_BYTES = 2048;                                   // exptab, then Tables::hatab (Params::lds_tab)
 inline int lds_tab_for(int blocks) { return LDS_EXP_BYTES + ht_bytes_for(blocks); }
 inline bool hbm_plane(int cells_pad);
-// LDS of a workgroup: [exptab][hatab][flag plane unless it stays in HBM][bitmaps if used]
-inline size_t lds_bytes_for(int cells_pad, int lds_tab) {
+// LDS of a workgroup: [exptab][hatab][flag plane unless it stays in HBM][bitmaps if used][zombie table if Z > 64]
+inline size_t lds_zl_offset(int cells_pad, int lds_tab) {
   return (size_t)lds_tab + (hbm_plane(cells_pad) ? 0u : (size_t)cells_pad) +
          (use_bitmaps(cells_pad) ? (size_t)BM_COUNT * 4u * (size_t)bm_words_for(cells_pad) : 0u);
+}
+inline size_t lds_bytes_for(int cells_pad, int lds_tab, int Z, int P) {
+  return lds_zl_offset(cells_pad, lds_tab) + zl_bytes_for(Z, P);
 }
 // flag planes above this size stay in HBM (Core<.., HBM_PLANE>): staging them would leave < 12 wavefronts per CU
 constexpr int LDS_PLANE_MAX = 12 * 1024;

@@ -138,6 +138,12 @@ struct WaveGfx950 {
   static SF_DEV V lds_u8_any(const uint8_t *lds, V idx) { return (uint32_t)lds[idx]; }  // every lane: idx must be valid
   static SF_DEV uint32_t ulds_u8(const uint8_t *lds, uint32_t idx) { return uni((uint32_t)lds[idx]); }
   static SF_DEV V lds_u32(const uint32_t *lds, V idx, P pred) { return pred ? lds[idx] : 0u; }
+  // wave-uniform dword in LDS (the zombie tables of worlds with more than 64 zombies, sf_core.hpp ZL)
+  static SF_DEV uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) { return uni(lds[idx]); }
+  static SF_DEV void ulds_store_u32(uint32_t *lds, uint32_t idx, uint32_t val) {
+    lds[idx] = val;  // every lane writes the same dword
+    __builtin_amdgcn_wave_barrier();
+  }
   // the same with a wave-uniform first factor, which stays in an SGPR (VOP2 src0)
   static SF_DEV V mul24_su(uint32_t a, V b) {
     uint32_t r;

@@ -16,41 +16,41 @@
 namespace sf {
 
 // same variant choice as the HIP launchers: big flag planes stay in "HBM" (here: the host arrays)
-template <int NB>
+template <int NB, bool ZL>
 static void run_reset(const Params &p, const uint64_t *tb, const uint64_t *serial) {
-  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab));
+  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P));
   for (int a = 0; a < p.A; ++a) {
     if (!hbm_plane(p.cells_pad))
-      Core<WaveEmu, NB, false, true>::reset_body(lds.data(), p, a, tb, serial);
+      Core<WaveEmu, NB, false, true, ZL>::reset_body(lds.data(), p, a, tb, serial);
     else if (use_bitmaps(p.cells_pad))
-      Core<WaveEmu, NB, true, true>::reset_body(lds.data(), p, a, tb, serial);
+      Core<WaveEmu, NB, true, true, ZL>::reset_body(lds.data(), p, a, tb, serial);
     else
-      Core<WaveEmu, NB, true, false>::reset_body(lds.data(), p, a, tb, serial);
+      Core<WaveEmu, NB, true, false, ZL>::reset_body(lds.data(), p, a, tb, serial);
   }
 }
-template <int NB>
+template <int NB, bool ZL>
 static void run_step(const Params &p, const uint8_t *cmds, int k) {
-  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab));
+  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P));
   for (int a = 0; a < p.A; ++a) {
     if (!hbm_plane(p.cells_pad))
-      Core<WaveEmu, NB, false, true>::step_body(lds.data(), p, a, cmds, k);
+      Core<WaveEmu, NB, false, true, ZL>::step_body(lds.data(), p, a, cmds, k);
     else if (use_bitmaps(p.cells_pad))
-      Core<WaveEmu, NB, true, true>::step_body(lds.data(), p, a, cmds, k);
+      Core<WaveEmu, NB, true, true, ZL>::step_body(lds.data(), p, a, cmds, k);
     else
-      Core<WaveEmu, NB, true, false>::step_body(lds.data(), p, a, cmds, k);
+      Core<WaveEmu, NB, true, false, ZL>::step_body(lds.data(), p, a, cmds, k);
   }
 }
 
-template <int NB>
+template <int NB, bool ZL>
 static void run_step_half(const Params &p, const uint8_t *cmds, int phase) {
-  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab));
+  std::vector<uint8_t> lds(lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P));
   for (int a = 0; a < p.A; ++a) {
     if (!hbm_plane(p.cells_pad))
-      Core<WaveEmu, NB, false, true>::step_half_body(lds.data(), p, a, cmds, phase);
+      Core<WaveEmu, NB, false, true, ZL>::step_half_body(lds.data(), p, a, cmds, phase);
     else if (use_bitmaps(p.cells_pad))
-      Core<WaveEmu, NB, true, true>::step_half_body(lds.data(), p, a, cmds, phase);
+      Core<WaveEmu, NB, true, true, ZL>::step_half_body(lds.data(), p, a, cmds, phase);
     else
-      Core<WaveEmu, NB, true, false>::step_half_body(lds.data(), p, a, cmds, phase);
+      Core<WaveEmu, NB, true, false, ZL>::step_half_body(lds.data(), p, a, cmds, phase);
   }
 }
 
@@ -77,12 +77,12 @@ static void run_observe(const Params &p, float *out) {
       for (int z = 0; z < p.Z; ++z)
         if (v.zom(ZW_POS, z) & ZF_ALIVE) {
           int s = obs_window_slot(v.zom(ZW_POS, z) & POS_MASK, center);
-          if (s >= 0) occ[s] |= (uint32_t)(z + 1) << 8;
+          if (s >= 0) occ[s] |= (uint32_t)(z + 1) << OCC_Z_SH;
         }
       for (int b = 0; b < p.B; ++b)
         if (v.bul(BW_A, b) & BA_REF) {
           int s = obs_window_slot(v.bul(BW_A, b) & POS_MASK, center);
-          if (s >= 0) occ[s] |= (uint32_t)(b + 1) << 16;
+          if (s >= 0) occ[s] |= (uint32_t)(b + 1) << OCC_B_SH;
         }
       for (int w = 0; w < W2; ++w) {
         const int i = pos_r(center) - SF_OBS_WINDOW / 2 + w / SF_OBS_WINDOW;
@@ -116,31 +116,43 @@ struct CpuRT {
   void zero(void *d, size_t n) { memset(d, 0, n); }
   int sync() { return SF_OK; }
   int launch_reset(const Params &p, int NB, const uint64_t *tb, const uint64_t *serial) {
+    if (large_pools(p.Z, p.P)) {
+      run_reset<4, true>(p, tb, serial);
+      return SF_OK;
+    }
     switch (NB) {
-      case 1: run_reset<1>(p, tb, serial); break;
-      case 2: run_reset<2>(p, tb, serial); break;
-      case 3: run_reset<3>(p, tb, serial); break;
-      default: run_reset<4>(p, tb, serial); break;
+      case 1: run_reset<1, false>(p, tb, serial); break;
+      case 2: run_reset<2, false>(p, tb, serial); break;
+      case 3: run_reset<3, false>(p, tb, serial); break;
+      default: run_reset<4, false>(p, tb, serial); break;
     }
     return SF_OK;
   }
   int launch_step(const Params &p, int NB, const uint8_t *cmds, int k) {
+    if (large_pools(p.Z, p.P)) {
+      run_step<4, true>(p, cmds, k);
+      return SF_OK;
+    }
     switch (NB) {
-      case 1: run_step<1>(p, cmds, k); break;
-      case 2: run_step<2>(p, cmds, k); break;
-      case 3: run_step<3>(p, cmds, k); break;
-      default: run_step<4>(p, cmds, k); break;
+      case 1: run_step<1, false>(p, cmds, k); break;
+      case 2: run_step<2, false>(p, cmds, k); break;
+      case 3: run_step<3, false>(p, cmds, k); break;
+      default: run_step<4, false>(p, cmds, k); break;
     }
     return SF_OK;
   }
   bool can_rank() const { return false; }  // (a launch order only matters where arenas run side by side)
-  int launch_rank(const Params &, uint16_t *) { return SF_OK; }
+  int launch_rank(const Params &, uint32_t *) { return SF_OK; }
   int launch_step_half(const Params &p, int NB, const uint8_t *cmds, int phase) {
+    if (large_pools(p.Z, p.P)) {
+      run_step_half<4, true>(p, cmds, phase);
+      return SF_OK;
+    }
     switch (NB) {
-      case 1: run_step_half<1>(p, cmds, phase); break;
-      case 2: run_step_half<2>(p, cmds, phase); break;
-      case 3: run_step_half<3>(p, cmds, phase); break;
-      default: run_step_half<4>(p, cmds, phase); break;
+      case 1: run_step_half<1, false>(p, cmds, phase); break;
+      case 2: run_step_half<2, false>(p, cmds, phase); break;
+      case 3: run_step_half<3, false>(p, cmds, phase); break;
+      default: run_step_half<4, false>(p, cmds, phase); break;
     }
     return SF_OK;
   }

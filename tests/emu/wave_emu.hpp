@@ -267,6 +267,14 @@ struct WaveEmu {
     for (int i = 0; i < 64; ++i) r.v[i] = ((pred.m >> i) & 1ull) ? lds[idx.v[i]] : 0u;
     return r;
   }
+  static uint32_t ulds_u32(const uint32_t *lds, uint32_t idx) {
+    EMU_SOP();
+    return lds[idx];
+  }
+  static void ulds_store_u32(uint32_t *lds, uint32_t idx, uint32_t val) {
+    EMU_SOP();
+    lds[idx] = val;
+  }
   static void rng_prio_end() {}
   static constexpr bool FUSED_ROUND = false;  // (the fused asm form of the round exists on the device only)
   static V rng_round(V &, uint32_t, V, V, V, V, const uint32_t *, uint32_t &) { return V(0u); }

@@ -64,7 +64,8 @@ def run_case(name):
     digests, obs = [], {}
     for s in range(steps + 1):
         od, rd = o.dump(0), r.dump()
-        if r.over or od.hdr.done:
+        assert not r.over, "%s step %d: the reference holds more entities than the configuration's pools" % (name, s)
+        if od.hdr.done:
             break
         d = reftick.first_difference(rd, reftick.arrays_of(od))
         assert d is None, "%s step %d: %s" % (name, s, d)

@@ -95,6 +95,25 @@ def test_a_list_that_does_not_fit_is_counted(cnn):
     assert pb.sparse_overflows() == 0  # cleared by the query
 
 
+def test_a_list_capacity_above_the_kernels_limit_is_refused(cnn):
+    """Above SF_POLICY_LIST_MAX (2048) the network's kernels would call an agent with 2048 < count <= cap "overflowed"
+    while sf_observe_overflow_device, which only knows cap, never wrote its dense row: both entry points refuse such a
+    cap (SF_ERR_ARG), so "the list did not fit" means count > cap (or the marker) on both sides."""
+    B, cap = 4, 4096
+    pb = policy.PolicyBatch(policy.init_parameters(0), B)
+    keys = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    vals = torch.zeros((B, cap), dtype=torch.float32, device="cuda")
+    counts, pov = torch.zeros(B, dtype=torch.int32, device="cuda"), torch.zeros((B, 160), device="cuda")
+    probs, value = torch.zeros((B, 9), device="cuda"), torch.zeros(B, device="cuda")
+    dense = torch.full((B, 32 * 31 * 31), float("nan"), device="cuda")
+    for d in (None, dense.data_ptr()):
+        with pytest.raises(env.StrikeForceError, match="SF_POLICY_LIST_MAX"):
+            pb.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), cap, B, probs.data_ptr(),
+                              value.data_ptr(), d_dense_ptr=d)
+    pb.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), 2048, B, probs.data_ptr(), value.data_ptr())
+    pb.synchronize()
+
+
 def test_crowded_windows_are_marked_not_truncated():
     """MAXCAP (64 humans, 64 zombies, 256 bullet slots on 48 x 48): windows with more occupied cells than the kernel has
     records take the dense call's slow path; the list form must say so (count 0xffffffff) instead of handing over a partial

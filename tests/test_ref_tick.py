@@ -29,8 +29,8 @@ EVENTS = {}
 
 def lockstep(w, player, tb, serial, steps, cmd_seed, observe_every=0, min_steps=1, native_caps=True):
     """Reference and oracle side by side; returns the number of steps compared (the run stops when the game ends —
-    the reference's own check_end() and the oracle's are compared at every loop top — or when the reference's
-    population outgrows the configuration's slot pools, 64 / 64 / 256 against its own 9000)."""
+    the reference's own check_end() and the oracle's are compared at every loop top).  A reference population that
+    outgrows the configuration's slot pools fails the run: native runs take the pools of a whole game, ref_cases.POOLS."""
     o = Oracle(w)
     r = reftick.RefTick(w, player, native_caps=native_caps)
     try:
@@ -50,8 +50,7 @@ def lockstep(w, player, tb, serial, steps, cmd_seed, observe_every=0, min_steps=
             r.step(cmds[s, 0, :1])
             od = o.dump(0)
             rd = r.dump()
-            if r.over:  # more live entities than the configuration's caps hold (the reference's own are 9000): stop here
-                break
+            assert not r.over, "step %d: the reference holds %d live entities beyond the configuration's pools" % (s, r.over)
             # SURVEY §8c golden item 5: the draws of every phase of every step (pins the ORDER in which phases draw)
             assert o.phase_draws(0) == r.phase_draws, "step %d: draws per phase %s, the reference's %s" % (s, o.phase_draws(0), r.phase_draws)
             assert r.phase_draws[5] == 0 and r.phase_draws[1] == 1 and r.phase_draws[3] == 1
@@ -85,8 +84,8 @@ def test_timer_long_run_level_10_account():
     """Timer mode with the reference's own level-10 account (15000 Hp): 2500 steps = 5000 frames, populations of
     zombies and NPC humans at their steady state, NPC humans shooting (human_rnpc_bot), kills, loot, level-ups."""
     w = native(abi.MODE_TIMER, 4, RICH, map_seed=5, wall_p=0.03)
-    n = lockstep(w, RICH, 1771155561, 1073741823, 2500, 99, observe_every=100, min_steps=1500)
-    assert n >= 1500
+    n = lockstep(w, RICH, 1771155561, 1073741823, 2500, 99, observe_every=100, min_steps=2500)
+    assert n == 2500
 
 
 def test_shipped_world_fresh_player():
@@ -96,8 +95,17 @@ def test_shipped_world_fresh_player():
 
 
 def test_shipped_world_level_10_account_long():
+    """2000 steps of a level-3 Timer game: the 65th zombie is alive from step 1642 on (the reference's own pool holds 9000)."""
     w = native(abi.MODE_TIMER, 3, RICH, maps="shipped")
-    lockstep(w, RICH, 1700000999, 55555, 2000, 31, observe_every=100, min_steps=1000)
+    assert lockstep(w, RICH, 1700000999, 55555, 2000, 31, observe_every=100, min_steps=2000) == 2000
+
+
+def test_a_whole_timer_game_on_the_shipped_maps():
+    """Level 1 to the end of its frame clock, 7500 frames = 3750 steps (the reference's own clock is time(0),
+    gameplay.hpp:1145): 95 zombies and 49 exits at the end, every step compared.  (Level 3, 11 250 steps, 237 zombies:
+    tests/golden/ref_traj.json `shipped-timer-level3-full`, compared the same way when the file is written.)"""
+    w = native(abi.MODE_TIMER, 1, RICH, maps="shipped")
+    assert lockstep(w, RICH, 1700000999, 55555, 3750, 31, observe_every=250, min_steps=3750) == 3750
 
 
 @pytest.mark.parametrize("level", [1, 3])
