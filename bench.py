@@ -268,17 +268,17 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the simulator has no CPU path")
-    # SF_BENCH_BACKEND=gloo + SF_BENCH_DEVICE=0 let the N > 1 control flow be rehearsed on a one-GPU box (two ranks on
-    # one card; RCCL refuses that).  The driver's multi-GPU runs use neither: backend nccl (= RCCL), device = LOCAL_RANK.
+    # The one RCCL communicator of a multi-GPU run is the library's own (sf_comm_init, behind the C-ABI): torch.distributed
+    # only carries rank 0's 128-byte id, the barriers and the MAX over ranks, and does that over gloo — a second RCCL
+    # communicator (torch's "nccl" group) beside the library's would double the bootstrap and the device buffers for
+    # nothing.  SF_BENCH_BACKEND=gloo + SF_BENCH_DEVICE=0 rehearse the N > 1 control flow on a one-GPU box (two ranks on
+    # one card, which RCCL refuses): the records then go through host memory.  The driver's runs use neither.
     backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
     local = int(os.environ.get("SF_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
 
     w = config.baseline_workload(args.workload, arenas=args.arenas, device=local)
     cfg = w.cfg
@@ -293,7 +293,9 @@ def main():
     # it is then repeated REPEATS times on fresh command windows, each repeat bracketed like the first, and the line
     # reports the median (min / max beside it).  Every repeat times EXACTLY --steps steps.
     REPEATS, SHORT_S = 21, 0.05
-    total = pre + args.warmup + args.steps * REPEATS
+    # the repeats' command windows are generated (and uploaded) only if the first timed region turns out short: the
+    # default --steps 1000 never repeats, and 21 windows of it would be 88 MB per agent for nothing
+    total = pre + args.warmup + args.steps
     cmds, _ = config.bench_commands(args.arenas, cfg.n_agents, total, seed0=shard.command_seed(w, rank))
     d_cmds = torch.from_numpy(cmds).cuda()  # resident in HBM before the timed region
     stride = args.arenas * cfg.n_agents
@@ -303,11 +305,10 @@ def main():
     gather = world > 1 or os.environ.get("SF_BENCH_FORCE_GATHER") == "1"
     n_rec = args.arenas * cfg.n_agents * 8
     rccl = gather and backend == "nccl"
-    torch_gather = False
     if rccl:
-        # the communicator is the library's own (sf_comm_init); torch.distributed only carries rank 0's unique id.
-        # Should the library's RCCL refuse to come up on this node, every rank falls back together to the same
-        # all-gather through torch.distributed (same RCCL collective, issued by torch) and the line says so.
+        # the communicator is the library's own (sf_comm_init); torch.distributed (gloo) only carries rank 0's unique id.
+        # Should the library's RCCL refuse to come up on this node, every rank falls back together to gathering the
+        # records through host memory (gloo) and the line says so.
         res_all = [torch.zeros(world * n_rec, dtype=torch.int32, device="cuda") for _ in range(2)]
         ok = 1
         try:
@@ -323,13 +324,11 @@ def main():
             except env.StrikeForceError:
                 ok = 0
         if world > 1:
-            t_ok = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            t_ok = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
             ok = int(t_ok.item())
         if not ok:
-            rccl, torch_gather = False, world > 1
-            res_local = [torch.zeros(n_rec, dtype=torch.int32, device="cuda") for _ in range(2)]
-            pending = [None, None]
+            rccl = False  # (`gather` stays on: the host path below)
     launches = [0]
 
     def run(first, count):
@@ -340,14 +339,7 @@ def main():
             if rccl:  # sf_results_allgather: snapshot on the launch stream, ncclAllGather on the library's side stream
                 g.results_allgather(res_all[launches[0] & 1].data_ptr())
                 launches[0] += 1
-            elif torch_gather:
-                j = launches[0] & 1
-                launches[0] += 1
-                if pending[j] is not None:
-                    pending[j].wait()
-                g.results_device(res_local[j].data_ptr())
-                pending[j] = dist.all_gather_into_tensor(res_all[j], res_local[j], async_op=True)
-            elif gather:  # rehearsal backend (gloo, ranks sharing one card): through host memory
+            elif gather:  # rehearsal (ranks sharing one card), or the library's RCCL did not come up: through host memory
                 res = torch.zeros(n_rec, dtype=torch.int32, device="cuda")
                 g.results_device(res.data_ptr())
                 torch.cuda.current_stream().synchronize()
@@ -357,11 +349,6 @@ def main():
     def drain():
         if rccl:
             g.comm_wait(host_too=True)
-        elif torch_gather:
-            for j in range(2):
-                if pending[j] is not None:
-                    pending[j].wait()
-                    pending[j] = None
 
     run(0, pre)  # untimed pre-roll: full-length launches, populations and clocks at steady state
     run(pre, args.warmup)
@@ -382,13 +369,17 @@ def main():
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
         if world > 1:  # MAX over ranks
-            tt = torch.tensor([t], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            tt = torch.tensor([t], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t = float(tt.item())
         return t
 
     dts = [timed(pre + args.warmup)]
     if dts[0] < SHORT_S:  # (the same decision on every rank: dts[0] is the maximum over ranks)
+        total = pre + args.warmup + args.steps * REPEATS
+        cmds, _ = config.bench_commands(args.arenas, cfg.n_agents, total, seed0=shard.command_seed(w, rank))  # (same stream, longer)
+        d_cmds = torch.from_numpy(cmds).cuda()
+        torch.cuda.synchronize()
         for r_ in range(1, REPEATS):
             dts.append(timed(pre + args.warmup + r_ * args.steps))
     dt = float(np.median(dts))
@@ -574,8 +565,9 @@ def main():
                        "arenas_per_gpu": args.arenas, "steps_per_launch": steps_per_launch, "preroll_steps": pre,
                        "parallelism": ("arena-sharded x%d, no data-path collective; result records all-gathered over "
                                        "RCCL (%s) after each launch"
-                                       % (world, "sf_results_allgather" if rccl else "torch.distributed fallback"
-                                          if torch_gather else "host rehearsal path")) if world > 1 else
+                                       % (world, "sf_results_allgather: the library's own communicator, the only one of the job"
+                                          if rccl else "host path over gloo: the library's RCCL did not come up, or a rehearsal"))
+                                      if world > 1 else
                                       "one GPU, arena-sharded by construction (no data-path collective)"},
             # contract figure: ALGORITHMIC bytes per launch / measured launch time against HBM peak.  `traffic` is the
             # HBM bytes the counters saw for a launch of this length (None when that shape was not profiled): the arena
@@ -593,9 +585,9 @@ def main():
         }
         if world > 1:
             # ncclCommCount of the library's communicator (sf_comm_ranks): what RCCL itself says took part; None on the
-            # torch.distributed fallback / host rehearsal path.  The multi-rank sf_results_allgather path is unmeasured on
-            # hardware until a SCALE record exists.
+            # host path.  The multi-rank sf_results_allgather path is unmeasured on hardware until a SCALE record exists.
             out["rccl_ranks"] = rccl_ranks
+            out["multi_rank_gather"] = "unmeasured on hardware before this run (no SCALE record of an earlier round exists)"
         obs_bytes = args.arenas * cfg.n_agents * (30752 * 4 + 961 * 8)
         if obs_n:
             out["interactive"] = {
@@ -660,7 +652,7 @@ def main():
             }
         if world == 1 and not args.no_other_configs:
             out["other_configs"] = other_configs(args, local, torch, config, env, args.workload)
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:  # rank 0, after the timed region, at any N (the reference itself on one host core)
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -271,6 +271,13 @@ int sf_done_device(sf_env *env, uint8_t *d_out);
 
 /* ---- parity / tooling ---------------------------------------------------------------------- */
 int sf_state_digest(sf_env *env, uint64_t *out_host); /* one 64-bit digest per arena */
+/* Generator draws (random.hpp:54-62 `_rand()`) of every arena's LAST iteration by phase, out[arenas][6]: zombie_action
+ * (gameplay.hpp:654-693), the first update_bull (:1059-1100: always 1), human_action (:965-1012: the NPC commands + the
+ * sweep direction), the second update_bull (1), the next loop top's spawns (:1444-1449), everything else (0:
+ * portal_damage, update_tmp and the hits draw nothing).  The state digest pins the TOTAL (jomle); this pins the order in
+ * which the phases draw (SURVEY.md §8c golden item 5).  After sf_step_begin: the first two entries are of the running
+ * iteration, the others still of the one before. */
+int sf_phase_draws(sf_env *env, int32_t *out_host);
 int sf_dump_arena(sf_env *env, int32_t arena, sf_arena_hdr *hdr, sf_human_rec *humans,
                   sf_zombie_rec *zombies, sf_bullet_rec *bullets, sf_portal_rec *portals,
                   uint8_t *cell_flags, int32_t *cell_dmg, int32_t *cell_portal);

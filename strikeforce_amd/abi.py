@@ -151,6 +151,11 @@ def bind(lib, prefix):
     g("step_begin").argtypes = [vp]
     g("step_end").argtypes = [vp, C.c_char_p]
     g("agent_alive").argtypes = [vp, C.POINTER(C.c_uint8)]
+    # (the oracle keeps its own per-arena entry, sfo_phase_draws, with 64-bit counts; a library of an earlier round,
+    # loaded for an A/B through SF_LIBRARY_PATH, lacks the entry)
+    if prefix != "sfo_" and hasattr(lib, prefix + "phase_draws"):
+        g("phase_draws").argtypes = [vp, C.POINTER(C.c_int32)]
+        g("phase_draws").restype = C.c_int
     for n in ("reset", "step", "observe", "results", "done", "state_digest", "dump_arena", "step_begin", "step_end",
               "agent_alive"):
         g(n).restype = C.c_int

@@ -849,6 +849,10 @@ int sf_done(sf_env *env, uint8_t *out_host) {
   SF_ENV(env);
   return env->e.done_host(out_host);
 }
+int sf_phase_draws(sf_env *env, int32_t *out_host) {
+  SF_ENV(env);
+  return env->e.phase_draws_host(out_host);
+}
 int sf_step_begin(sf_env *env) {
   SF_ENV(env);
   return env->e.step_begin();

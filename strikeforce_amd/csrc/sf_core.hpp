@@ -82,6 +82,8 @@ struct Core {
     uint32_t jomle;
     uint32_t tb_lo, tb_hi, sr_lo, sr_hi;
     uint32_t dirty;  // the LDS flag plane differs from HBM
+    // generator draws of the last step by phase (SC_PD01 .. SC_PD45, sf_phase_draws): pins the ORDER in which phases draw
+    uint32_t pd01, pd23, pd45;
 #ifdef SF_DIAG_STAMPS
     V dacc;  // diagnostic build only (tools/diag_stamps.sh): wave cycles per tick phase, lane = phase
     uint32_t dlast;
@@ -220,6 +222,14 @@ struct Core {
 #endif
     SF_PROF(PH_WARM);
     if (S.warm >= 1024u) return;
+#ifdef SF_EXP_FREE_WARMUP
+    // timing build only (round 4): three of four warm-up draws cost nothing — the bound of running the next episode's
+    // generator in the idle lanes of the game's own rounds.  Wrong numbers by construction; never the product library.
+    if (S.warm & 3u) {
+      ++S.warm;
+      return;
+    }
+#endif
     uint32_t j2 = 18u + S.warm;
     if (S.warm < 18u) {
       draw_core<false>(S.rl2, S.rus, S.rseed2, j2, S.xt, p);
@@ -624,6 +634,18 @@ struct Core {
       if (!b) falls |= bit;
     }
     uint64_t movers = (todo & ~W::ballot(hnear != 0u)) | falls;
+#ifdef SF_EXP_ZLOOP_FREE
+    // timing build only (round 4): the draw loop keeps its draws (one, two or three per zombie, in about the real
+    // proportions) and loses everything else — slot lookup, free-cell test, "is a zombie there now", the move: the bound
+    // of ANY restructuring of the per-zombie decision logic (lane-parallel speculation over the draw stream included).
+    // Nobody moves: wrong by construction; never the product library.
+    for (int nz_ = W::popc64(movers); nz_ > 0; --nz_) {
+      if (mod5(draw(S, lds, p)) < 2u) continue;
+      if (draw(S, lds, p) & 1u) continue;
+      (void)draw(S, lds, p);
+    }
+    movers = 0ull;
+#endif
     while (movers) {
       const uint32_t z = (uint32_t)W::ctz64(movers);
       movers &= movers - 1ull;
@@ -1812,15 +1834,20 @@ struct Core {
     if (S.done) return;
     // the two half-ticks share `update_tmp; hit_human; hit_zombie; ++frame; update_bull` (G:1457-1463,1465-1471)
     SF_STAMP(S, 0);
+    uint32_t rest = 0u;  // draws outside the five drawing phases (none: portal_damage, update_tmp and the hits draw nothing)
     SF_NOUNROLL for (int half = (PHASE == 2 ? 1 : 0); half < (PHASE == 1 ? 1 : 2); ++half) {
+      const uint32_t j0 = S.jomle;
       if (half == 0) {
         zombie_action(S, lds, p);
         SF_STAMP(S, 1);
-        portal_damage(S, lds, p);
-        SF_STAMP(S, 2);
       } else {
         human_action(S, lds, p, a);
         SF_STAMP(S, 3);
+      }
+      const uint32_t j1 = S.jomle;
+      if (half == 0) {
+        portal_damage(S, lds, p);
+        SF_STAMP(S, 2);
       }
       if (p.auto_reset) prewarm(S, lds, p, S.wrate);  // warm-up draws of the next episode, spread over the step so that
       SF_STAMP(S, 4);
@@ -1831,14 +1858,23 @@ struct Core {
       ++S.frame;  // updmap G:489-495 clears render-only bits
       if (p.auto_reset) prewarm(S, lds, p, S.wrate);
       SF_STAMP(S, 4);
+      const uint32_t j2 = S.jomle;
       update_bull(S, lds, p);
       SF_STAMP(S, 7);
+      const uint32_t w = ((j1 - j0) & 0xffffu) | ((S.jomle - j2) << 16);
+      rest += j2 - j1;
+      if (half == 0)
+        S.pd01 = w;
+      else
+        S.pd23 = w;
     }
     if (PHASE == 1) return;
     ++S.steps;
     // the loop top; when the episode ends and auto_reset is on, once more for the episode that begins
     SF_NOUNROLL for (int pass = 0; pass < 2; ++pass) {
+      const uint32_t j3 = S.jomle;
       loop_top(S, lds, p, a);
+      if (pass == 0) S.pd45 = ((S.jomle - j3) & 0xffffu) | (rest << 16);
       if (!S.done || pass == 1) break;
       if (S.ended < 255) ++S.ended;  // episodes that ended during this launch (sf_done with auto_reset)
       ++S.episodes;
@@ -1930,6 +1966,7 @@ struct Core {
     S.tb_lo = W::readlane(sc, SC_TB_LO), S.tb_hi = W::readlane(sc, SC_TB_HI);
     S.sr_lo = W::readlane(sc, SC_SR_LO), S.sr_hi = W::readlane(sc, SC_SR_HI);
     S.warm = W::readlane(sc, SC_WARM);
+    S.pd01 = W::readlane(sc, SC_PD01), S.pd23 = W::readlane(sc, SC_PD23), S.pd45 = W::readlane(sc, SC_PD45);
     if (!HBM_PLANE) W::copy_g2l(lds, p.flags + (size_t)a * (size_t)p.cells_pad, (uint32_t)p.cells_pad);
     S.dirty = 0u;
     draw_issue(S, p);  // the lookup of the next draw (S.la) is not part of the stored state
@@ -2004,6 +2041,7 @@ struct Core {
     W::setlane(sc, SC_SR_LO, S.sr_lo), W::setlane(sc, SC_SR_HI, S.sr_hi);
     W::setlane(sc, SC_DRAWS, S.jomle - (18u + 1024u));  // _rand() calls since the episode's _srand: jomle counts them
     W::setlane(sc, SC_WARM, S.warm);
+    W::setlane(sc, SC_PD01, S.pd01), W::setlane(sc, SC_PD23, S.pd23), W::setlane(sc, SC_PD45, S.pd45);
     if constexpr (ZL) {
       W::setlane(sc, SC_LOAD, zlive_n + (uint32_t)W::popc64(W::ballot(((S.hfl & HF_ALIVE) != 0u) & W::ltu(ln, (uint32_t)p.H))));
       W::setlane(sc, SC_ZWN, S.zwn);
@@ -2047,6 +2085,7 @@ struct Core {
   static SF_DEV void reset_body(uint8_t *lds, const Params &p, int a, const uint64_t *tb, const uint64_t *serial) {
     Arena S;
     S.episodes = 0, S.ended = 0;
+    S.pd01 = S.pd23 = S.pd45 = 0u;
     lds = tables(S, lds, p, a);
     S.rl2 = V(RL_ZERO), S.rseed2 = V(0u), S.warm = 0u, S.wrate = 1u;
     if constexpr (ZL) S.zwhi = (uint32_t)zw_for(p.Z), S.pwhi = (uint32_t)zw_for(p.P);  // store() writes the whole tables once: slots beyond zwn / pwn are zero in HBM from here on

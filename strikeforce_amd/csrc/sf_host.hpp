@@ -195,7 +195,7 @@ struct Env {
   uint64_t *d_tb = nullptr, *d_serial = nullptr;
   uint8_t *d_cmd = nullptr;
   uint32_t *d_perm = nullptr;  // k_step's launch order (k_rank): arenas by population, for long launches
-  int balance = 1;             // SF_BALANCE=0 switches the ordering off, 2 forces it on HBM-plane maps too (A/B measurements)
+  int balance = 1;             // SF_BALANCE=0 switches the ordering off (A/B measurements)
   int steps_since_rank = 1 << 30;  // the order is renewed every >= 100 steps (populations change by one every 20-25 steps)
   float *d_obs = nullptr;
   uint32_t *d_nzprev = nullptr;      // [A * n_agents][961] which floats of the delta-tracked buffer are non-zero
@@ -238,7 +238,7 @@ struct Env {
     NB = large_pools(p.Z, p.P) ? 4 : nb_for(p.B);
     {
       const char *e = getenv("SF_BALANCE");  // (A/B measurements: SF_BALANCE=0 switches k_rank's launch order off)
-      balance = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
+      balance = (e && e[0] == '0') ? 0 : 1;
     }
     // tables: one shared player record (block 0) + npc (block 1), or one record per commanded human (blocks 0..15,
     // the account blobs of a lock-step match, gameplay.hpp:120-151) + npc (block 16)
@@ -385,9 +385,11 @@ struct Env {
     if (mid_step) return fail(SF_ERR_STATE, "sf_step_device between sf_step_begin and sf_step_end");
     // long launches: order the arenas by population first, so that the ones sharing a SIMD are of different loads (k_rank)
     Params q = p;
-    // Below 1024 arenas every arena has a SIMD of its own (the chip has 1024): nothing to order.  Maps whose flag plane
-    // stays in HBM gained nothing from the order in measurements (profiles/r04_rank_sweep.txt): left alone.
-    if (balance && k >= 8 && p.A >= 1024 && rt.can_rank() && (!hbm_plane(p.cells_pad) || balance == 2)) {
+    // Below 1024 arenas every arena has a SIMD of its own (the chip has 1024): nothing to order.  Measured for 2048 ...
+    // 16384 arenas, an arena count that is no multiple of 1024, and the maps whose flag plane stays in HBM
+    // (profiles/r04b_rank_sweep.txt): +1 % (2048) ... +14 % (5000) on configs[2], +4 % on configs[4], -0.6 % on configs[3]
+    // (every arena at its caps: nothing to order, k_rank's 7 us per 100 steps is what is left)
+    if (balance && k >= 8 && p.A >= 1024 && rt.can_rank()) {
       int rc;
       if (!d_perm && (rc = alloc(d_perm, (size_t)p.A))) return rc;
       if (steps_since_rank >= 100) {
@@ -501,6 +503,25 @@ struct Env {
     if (rc) return rc;
     for (int a = 0; a < p.A; ++a)
       out[a] = (uint8_t)(p.auto_reset ? sc[(size_t)a * SC_WORDS + SC_ENDED] : sc[(size_t)a * SC_WORDS + SC_DONE]);
+    return SF_OK;
+  }
+
+  // generator draws of every arena's last step by phase: out[A][6] = zombie_action, update_bull (1st), human_action,
+  // update_bull (2nd), the next loop top's spawns, everything else (0)
+  int phase_draws_host(int32_t *out) {
+    if (!out) return fail(SF_ERR_ARG, "null output buffer");
+    if (!was_reset) return fail(SF_ERR_STATE, "sf_phase_draws before sf_reset");
+    std::vector<int32_t> sc((size_t)p.A * SC_WORDS);
+    rt.d2h(sc.data(), p.scal, sc.size() * sizeof(int32_t));
+    int rc = rt.sync();
+    if (rc) return rc;
+    for (int a = 0; a < p.A; ++a) {
+      const uint32_t w[3] = {(uint32_t)sc[(size_t)a * SC_WORDS + SC_PD01], (uint32_t)sc[(size_t)a * SC_WORDS + SC_PD23],
+                             (uint32_t)sc[(size_t)a * SC_WORDS + SC_PD45]};
+      int32_t *o = out + (size_t)a * 6;
+      o[0] = (int32_t)(w[0] & 0xffffu), o[1] = (int32_t)(w[0] >> 16), o[2] = (int32_t)(w[1] & 0xffffu), o[3] = (int32_t)(w[1] >> 16);
+      o[4] = (int32_t)(w[2] & 0xffffu), o[5] = (int32_t)(w[2] >> 16);
+    }
     return SF_OK;
   }
 

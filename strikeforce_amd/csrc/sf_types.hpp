@@ -63,6 +63,9 @@ enum { SC_FRAME = 0, SC_KILLS, SC_TKILLS, SC_LOOT, SC_CHESTS, SC_JOMLE, SC_STEPS
        SC_LOAD /* live zombies + live humans when the state was stored: k_rank's key, not part of the game state */,
        SC_ZWN /* large slot pools (sf_core.hpp ZL): 64-slot words of the zombie table in use */,
        SC_PWN /* ... and of the exit table */,
+       // generator draws of the arena's last step by phase (sf_phase_draws), two 16-bit counts per word: zombie_action |
+       // first update_bull << 16; human_action | second update_bull << 16; the next loop top's spawns | everything else << 16
+       SC_PD01, SC_PD23, SC_PD45,
        SC_WORDS = 24 };
 constexpr int RNG_WORDS = 18;
 

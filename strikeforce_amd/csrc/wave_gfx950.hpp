@@ -10,6 +10,10 @@
 
 #define SF_DEV __device__ __forceinline__
 
+#if (defined(SF_EXP_SHORT_ROUND) || defined(SF_EXP_FREE_WARMUP) || defined(SF_EXP_ZLOOP_FREE)) && !defined(SF_EXPERIMENT_BUILD)
+#error "timing experiments (wrong results by construction): only together with -DSF_EXPERIMENT_BUILD"
+#endif
+
 namespace sf {
 
 // HBM pointers reach the kernels inside a by-value struct, where clang leaves them in the generic address
@@ -186,6 +190,7 @@ struct WaveGfx950 {
     uint32_t x;
     asm volatile("v_mad_i32_i24 %[x], %[d], %[us], %[bias]\n\t"
         "s_nop 1\n\t"
+#ifndef SF_EXP_SHORT_ROUND  // (timing experiment, round 4: what four vector instructions less per round would buy; wrong sums)
         "v_add_u32_dpp %[x], %[x], %[x] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
         "v_add_u32_dpp %[x], %[x], %[x] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
@@ -194,6 +199,7 @@ struct WaveGfx950 {
         "s_nop 1\n\t"
         "v_add_u32_dpp %[x], %[x], %[x] row_mirror row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
+#endif
         "v_add_u32_dpp %[x], %[x], %[x] row_bcast:15 row_mask:0x2 bank_mask:0xf\n\t"
         "v_sub_u32_sdwa %[x], %[x], %[x] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
         "v_lshl_add_u32 %[x], %[x], 1, %[bias]"
@@ -237,14 +243,18 @@ struct WaveGfx950 {
         "v_mad_i32_i24 %[x], %[d], %[us], %[bias]\n\t"
         "v_readlane_b32 %[o], %[d], 18\n\t"   // lane 18 carries seed 1 and the newest log: its power is the draw's value
         "s_lshr_b32 %[sg], %[o], 31\n\t"      // (signed residue lo16 - hi16: +65537 if negative; & 1023 keeps +1 of it)
+#ifndef SF_EXP_SHORT_ROUND
         "v_add_u32_dpp %[x], %[x], %[x] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#endif
         "s_add_i32 %[o], %[o], %[sg]\n\t"
         "s_and_b32 %[o], %[o], 0x3ff\n\t"
+#ifndef SF_EXP_SHORT_ROUND
         "v_add_u32_dpp %[x], %[x], %[x] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
         "v_add_u32_dpp %[x], %[x], %[x] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
         "v_add_u32_dpp %[x], %[x], %[x] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+#endif
         "s_nop 1\n\t"
         "v_add_u32_dpp %[x], %[x], %[x] row_bcast:15 row_mask:0x2 bank_mask:0xf\n\t"
         "v_sub_u32_sdwa %[x], %[x], %[x] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"

@@ -78,7 +78,7 @@ EXPORTS = ["sf_create", "sf_destroy", "sf_config_defaults", "sf_reset", "sf_step
            "sf_observe_device", "sf_observe_device_delta", "sf_observe_sparse_device", "sf_observe_overflow_device", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
            "sf_set_stream", "sf_synchronize", "sf_kernel_time", "sf_last_error", "sf_abi_version",
            "sf_comm_unique_id", "sf_comm_init", "sf_results_allgather", "sf_comm_wait", "sf_comm_ranks",
-           "sf_step_begin", "sf_step_end", "sf_step_end_device", "sf_agent_alive", "sf_agent_alive_device"]
+           "sf_step_begin", "sf_step_end", "sf_step_end_device", "sf_agent_alive", "sf_agent_alive_device", "sf_phase_draws"]
 
 
 class ArenaBatch:
@@ -150,6 +150,13 @@ class ArenaBatch:
         out = np.zeros((self.cfg.arenas, self.cfg.n_agents), dtype=np.uint8)
         self._ck(self.L.sf_agent_alive(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))), "sf_agent_alive")
         return out
+
+    def phase_draws(self, arena=None):
+        """Generator draws of the last step by phase [zombie_action, update_bull, human_action, update_bull, spawns, rest]:
+        of one arena (a list of six ints) or of all ([arenas][6] int32)."""
+        out = np.zeros((self.cfg.arenas, 6), dtype=np.int32)
+        self._ck(self.L.sf_phase_draws(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))), "sf_phase_draws")
+        return out if arena is None else [int(x) for x in out[arena]]
 
     def agent_alive_device(self, d_out_ptr):
         self._ck(self.L.sf_agent_alive_device(self.h, C.c_void_p(d_out_ptr)), "sf_agent_alive_device")

@@ -228,6 +228,7 @@ int sfe_agent_alive(sfe_env *env, uint8_t *out) { return env->e.agent_alive_host
 int sfe_observe(sfe_env *env, float *out) { return env->e.observe_host(out); }
 int sfe_results(sfe_env *env, int32_t *out) { return env->e.results_host(out); }
 int sfe_done(sfe_env *env, uint8_t *out) { return env->e.done_host(out); }
+int sfe_phase_draws(sfe_env *env, int32_t *out) { return env->e.phase_draws_host(out); }
 int sfe_state_digest(sfe_env *env, uint64_t *out) { return env->e.state_digest(out); }
 int sfe_dump_arena(sfe_env *env, int32_t a, sf_arena_hdr *hdr, sf_human_rec *hs, sf_zombie_rec *zs, sf_bullet_rec *bs,
                    sf_portal_rec *ps, uint8_t *cf, int32_t *cd, int32_t *cp) {

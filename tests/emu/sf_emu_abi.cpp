@@ -40,4 +40,9 @@ int sf_done(sf_env *env, uint8_t *out) { return env->e.done_host(out); }
 int sf_agent_alive(sf_env *env, uint8_t *out) { return env->e.agent_alive_host(out); }
 int sf_results(sf_env *env, int32_t *out) { return env->e.results_host(out); }
 int sf_state_digest(sf_env *env, uint64_t *out) { return env->e.state_digest(out); }
+int sf_phase_draws(sf_env *env, int32_t *out) { return env->e.phase_draws_host(out); }
+int sf_dump_arena(sf_env *env, int32_t a, sf_arena_hdr *hdr, sf_human_rec *hs, sf_zombie_rec *zs, sf_bullet_rec *bs,
+                  sf_portal_rec *ps, uint8_t *cf, int32_t *cd, int32_t *cp) {
+  return env->e.dump_arena(a, hdr, hs, zs, bs, ps, cf, cd, cp);
+}
 }

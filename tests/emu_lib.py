@@ -73,6 +73,11 @@ class Emu:
         assert self.L.sfe_agent_alive(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
         return out
 
+    def phase_draws(self, arena=None):
+        out = np.zeros((self.cfg.arenas, 6), dtype=np.int32)
+        assert self.L.sfe_phase_draws(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        return out if arena is None else [int(x) for x in out[arena]]
+
     def observe(self):
         out = np.empty((self.cfg.arenas, self.cfg.n_agents, abi.OBS_CHANNELS, abi.OBS_WINDOW, abi.OBS_WINDOW),
                        dtype=np.float32)

@@ -22,6 +22,9 @@ def _lockstep(name, arenas, steps, check_every=1, **kw):
             for a in range(arenas):
                 d = diff_dumps(o.dump(a).as_dict(), e.dump(a).as_dict())
                 assert d is None, "%s step %d arena %d: %s" % (name, s, a, d)
+                # the draws of every phase of the step (SURVEY §8c golden item 5: pins the ORDER in which phases draw)
+                assert s < 0 or e.phase_draws(a) == o.phase_draws(a), "%s step %d arena %d: draws per phase %s, the oracle's %s" % (
+                    name, s, a, e.phase_draws(a), o.phase_draws(a))
     assert (o.digest() == e.digest()).all()
     assert (o.results() == e.results()).all()
     assert (o.done() == e.done()).all()

@@ -33,6 +33,7 @@ def _dev_cmds(cmds):
 @pytest.mark.parametrize("name,steps", [("C1", 200), ("C2", 200), ("C3", 150), ("C4", 80), ("C5", 40), ("STRESS", 300),
                                         ("MAXCAP", 60), ("FLOORS", 200), ("NATIVE", 250)])
 def test_lockstep_state_parity(name, steps):
+    """Every field of every slot, every cell, the generator's registers — and the draws of every phase — after every step."""
     w, o, g = _pair(name, 3)
     cmds, _ = config.bench_commands(3, w.cfg.n_agents, steps)
     for s in range(-1, steps):
@@ -41,6 +42,9 @@ def test_lockstep_state_parity(name, steps):
         for a in range(3):
             d = diff_dumps(o.dump(a).as_dict(), _gpu_dump(g, a).as_dict())
             assert d is None, "%s step %d arena %d: %s" % (name, s, a, d)
+            # the draws of every phase of the step (SURVEY §8c golden item 5: pins the ORDER in which phases draw)
+            assert s < 0 or g.phase_draws(a) == o.phase_draws(a), "%s step %d arena %d: draws per phase %s, the oracle's %s" % (
+                name, s, a, g.phase_draws(a), o.phase_draws(a))
     assert (o.results() == g.results()).all()
     assert (o.done() == g.done()).all()
 

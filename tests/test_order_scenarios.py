@@ -126,7 +126,7 @@ def ref_player():
 
 def phase_draws(s):
     """draws of the last step by phase [zombie_action, update_bull, human_action, update_bull, spawns, rest]: from the
-    oracle / the reference driver; the emulator and the device have no such counter (the step's total is in jomle)"""
+    oracle, the reference driver, the emulator and the device (sf_phase_draws)"""
     if isinstance(s, RefSim):
         return s.r.phase_draws
     if hasattr(s.sim, "phase_draws"):
