@@ -472,6 +472,280 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   }
 }
 
+// ---- sf_observe_sparse_device: the observation as the list of its non-zero floats, one WAVEFRONT per (arena, agent) ----
+// The dense kernel above is built around streaming 123 KB per agent; for the list form that stream does not exist and
+// what is left — 16 384 wavefronts for 4096 agents, five workgroup barriers around a few hundred useful operations per
+// thread — costs the launch ramp of those wavefronts (~4.5 ns each: 0.075 ms, round 3).  Here one 64-lane wavefront does
+// the whole window, without workgroup barriers:
+//   0  the window's 961 flag bytes are requested first, all sixteen loads of a lane in flight at once
+//   1  every entity of the arena scatters itself into the window's occupant words (LDS atomics)
+//   2a the window cells are classified, 64 per pass: empty / plain static cell (one of 8 shared records, finished on the
+//      host) / needs a record of its own (an entity or a player-built object on it: ~20 cells) — those are queued
+//   2b the queued cells' records are built, one lane each, by the same describe() code as everywhere else; values that
+//      need a real x^(1/5) are queued once more and evaluated densely, one per lane (a human cell has ten of them)
+//   3  the list leaves in the dense buffer's scan order — channel, then row, then column — which is the order
+//      k_feat_list's partial sums are defined over: for every channel, the passes that hold a cell with that channel
+//      set (a 16-bit set per channel, from one OR per pass) emit their entries at base + rank-below-me (ballot + mbcnt)
+// Same values, same order, same counts as mode 3 of the dense kernel (tests/test_gpu_sparse_obs.py compares the list
+// with the dense observation float by float).  A window with more than OL_REC own records is "crowded" (count
+// 0xffffffff: the caller takes the dense call for that agent, as before; the dense kernel's own limit is 64).
+// LDS: 9.7 KB per wavefront, so that the 16 wavefronts a CU gets of a 4096-agent launch are resident together.
+constexpr int OL_REC = 48;                            // own records per window
+constexpr int OL_STRIDE = SF_OBS_CHANNELS + 1;        // (odd stride: the lanes of pass 2b write different banks)
+constexpr int OL_PASSES = (OBS_W2 + 63) / 64;         // 16
+constexpr int OL_POWQ = 384;                          // queued x^(1/5) evaluations per window; more are done in place
+constexpr int OL_CELLS = 640;                         // non-empty cells per window (walls included); more: "crowded"
+static_assert(OL_REC + OBS_CLASS_RECS <= 64 && OBS_W2 <= 1024, "a compact cell entry is window cell | slot << 10 in 16 bits");
+// LDS of one window, carved out of a caller-provided region (the stand-alone kernel's own, or k_step's dynamic region
+// once the step has stored its state): 16-byte aligned, OL_LDS_BYTES long
+struct ObsListLds {
+  uint32_t occ_rec[OL_REC * OL_STRIDE];  // the occupant words (961) while cells are classified, then the records
+  float crec[OBS_CLASS_RECS][SF_OBS_CHANNELS];
+  uint32_t cmask[OBS_CLASS_RECS], recmask[OL_REC], work_oc[OL_REC], powq_n;
+  uint16_t cell[OL_CELLS];               // the non-empty cells in window order: window cell | slot << 10
+  uint16_t work_w[OL_REC], powq[OL_POWQ];
+  uint8_t work_fl[OL_REC];
+};
+static_assert(OL_REC * OL_STRIDE >= OBS_W2 + 3, "the occupant words fit the record area");
+constexpr size_t OL_LDS_BYTES = (sizeof(ObsListLds) + 15) & ~(size_t)15;
+static_assert(OL_LDS_BYTES <= 10 * 1024, "16 wavefronts per CU");
+
+#ifdef SF_DIAG_OBS  // diagnostic build only (tools/r04_obs_stamps.py): wave cycles per phase of the list observation
+__device__ uint32_t sf_diag_obs[65536 * 8];  // [wave][phase]: the last launch's cycles (no atomics: they would be the measurement)
+#define OL_STAMP(ph)                                                                                      \
+  do {                                                                                                    \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                           \
+    if (threadIdx.x == 0 && blockIdx.x < 65536u) sf_diag_obs[blockIdx.x * 8u + (ph)] = (uint32_t)(t_ - ol_last_); \
+    ol_last_ = t_;                                                                                        \
+  } while (0)
+#else
+#define OL_STAMP(ph)
+#endif
+
+// bitwise OR over the wavefront's 64 lanes, as a wave-uniform value (DPP row steps, then the four row totals)
+static __device__ __forceinline__ uint32_t wave_or(uint32_t x) {
+  int v = (int)x;
+  v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+  v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);  // row_mirror: every lane holds its row's OR
+  return (uint32_t)(__builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) | __builtin_amdgcn_readlane(v, 32) |
+                    __builtin_amdgcn_readlane(v, 48));
+}
+static __device__ __forceinline__ uint32_t rank_below(uint64_t bal) {  // set bits of `bal` below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+}
+
+// The list observation of agent `agent` (= arena * n_agents + g) by the calling wavefront; L: OL_LDS_BYTES of LDS.
+static __device__ __forceinline__ void observe_list_wave(const Params &p, const ObsSparse &sp, int agent, ObsListLds &L) {
+#ifdef SF_DIAG_OBS
+  unsigned long long ol_last_ = __builtin_amdgcn_s_memtime();
+#endif
+  uint32_t *occ = L.occ_rec;
+  float *rec = reinterpret_cast<float *>(L.occ_rec);
+  const int l = (int)threadIdx.x;
+  const int a = agent / p.n_agents, g = agent % p.n_agents;
+  const uint32_t hf = gptr(p.hum)[((size_t)HW_FLAGS * p.A + a) * p.H + g];
+  const uint32_t center = gptr(p.hum)[((size_t)HW_POS * p.A + a) * p.H + g];
+  SF_GLOBAL float *pov = gptr(sp.pov) + (size_t)agent * (5 * SF_OBS_CHANNELS);
+  if ((hf & (HF_ALIVE | HF_CTRL)) != (HF_ALIVE | HF_CTRL)) {  // no observer: an empty list (uniform over the wave)
+    if (l == 0) gptr(sp.counts)[agent] = 0u;
+    for (int t = l; t < 5 * SF_OBS_CHANNELS; t += 64) pov[t] = 0.f;
+    return;
+  }
+  auto crowded = [&]() {  // the caller takes the dense call for this agent
+    if (l == 0) gptr(sp.counts)[agent] = 0xffffffffu;
+    for (int t = l; t < 5 * SF_OBS_CHANNELS; t += 64) pov[t] = 0.f;  // (sf_observe_overflow_device rewrites it from the dense row)
+  };
+  // ---- 0: the window's flag bytes --------------------------------------------------------------------------------
+  const int pteam = (int)((hf >> HF_TEAM_SH) & 255u);
+  const int r0 = pos_r(center) - SF_OBS_WINDOW / 2, c0 = pos_c(center) - SF_OBS_WINDOW / 2, f0 = pos_f(center);
+  const SF_GLOBAL uint8_t *plane = gptr(p.flags) + (size_t)a * p.cells_pad + (size_t)f0 * p.N * p.M;
+  uint32_t flv[OL_PASSES];
+#pragma unroll
+  for (int it = 0; it < OL_PASSES; ++it) {
+    const int w = it * 64 + l;
+    const int i = r0 + w / SF_OBS_WINDOW, j = c0 + w % SF_OBS_WINDOW;
+    flv[it] = (w < OBS_W2 && i >= 0 && j >= 0 && i < p.N && j < p.M) ? (uint32_t)plane[i * p.M + j] : 0u;
+  }
+  OL_STAMP(0);
+  // ---- 1: occupant words -------------------------------------------------------------------------------------
+  for (int w4 = l; w4 < (OBS_W2 + 3) / 4; w4 += 64) reinterpret_cast<u32x4 *>(occ)[w4] = (u32x4)(0u);
+  if (l < OBS_CLASS_RECS) L.cmask[l] = gptr(p.tab)->class_mask[l];
+  if (l == 0) L.powq_n = 0u;
+  for (int t = l; t < OBS_CLASS_RECS * SF_OBS_CHANNELS; t += 64) L.crec[t >> 5][t & 31] = gptr(p.tab)->class_rec[t >> 5][t & 31];
+  // the host-built constant table (the reference's libm): obs_map_fast.  One entry per lane, read by v_readlane below
+  const float t_in = l < 16 ? gptr(p.tab)->obs_in[l] : 0.f, t_out = l < 16 ? gptr(p.tab)->obs_out[l] : 0.f;
+  const int t_n = gptr(p.tab)->obs_n;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const ObsView v(p, a);  // entity tables where they lie: a window holds ~20 of them
+  if (l < p.H) {
+    if (v.hum(HW_FLAGS, l) & HF_OCC) {
+      const int s = obs_window_slot(v.hum(HW_POS, l), center);
+      if (s >= 0) atomicOr(&occ[s], (uint32_t)(l + 1));
+    }
+  }
+  // (large pools: only the words of the zombie table that are in use, sf_core.hpp ZL)
+  int zlim = p.Z;
+  if (large_pools(p.Z, p.P)) {
+    const int used = 64 * (int)gptr(p.scal)[(size_t)a * SC_WORDS + SC_ZWN];
+    zlim = used < p.Z ? used : p.Z;
+  }
+  for (int z = l; z < zlim; z += 64) {
+    const uint32_t zp = v.zom(ZW_POS, z);
+    if (zp & ZF_ALIVE) {
+      const int s = obs_window_slot(zp & POS_MASK, center);
+      if (s >= 0) atomicOr(&occ[s], (uint32_t)(z + 1) << OCC_Z_SH);
+    }
+  }
+  for (int b = l; b < p.B; b += 64) {
+    const uint32_t ba = v.bul(BW_A, b);
+    if (ba & BA_REF) {
+      const int s = obs_window_slot(ba & POS_MASK, center);
+      if (s >= 0) atomicOr(&occ[s], (uint32_t)(b + 1) << OCC_B_SH);
+    }
+  }
+  __syncthreads();
+  OL_STAMP(1);
+  // ---- 2a: classify; the non-empty cells are compacted, in window order ----------------------------------------
+  uint32_t nrec = 0u, ncell = 0u;  // wave-uniform
+#pragma unroll
+  for (int it = 0; it < OL_PASSES; ++it) {
+    const int w = it * 64 + l;
+    const uint32_t fl = flv[it], oc = w < OBS_W2 ? occ[w] : 0u;
+    const int cls = oc == 0u ? obs_class_of(fl) : -1;
+    const bool some = fl != 0u || oc != 0u, own = some && cls < 0;
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(some), balo = __builtin_amdgcn_ballot_w64(own);
+    if (some) {
+      uint32_t s = (uint32_t)cls;
+      if (own) {
+        const uint32_t r = nrec + rank_below(balo);
+        s = (uint32_t)OBS_CLASS_RECS + (r < (uint32_t)OL_REC ? r : 0u);
+        if (r < (uint32_t)OL_REC) L.work_w[r] = (uint16_t)w, L.work_oc[r] = oc, L.work_fl[r] = (uint8_t)fl;
+      }
+      const uint32_t c = ncell + rank_below(bal);
+      if (c < (uint32_t)OL_CELLS) L.cell[c] = (uint16_t)((uint32_t)w | (s << 10));
+    }
+    nrec += (uint32_t)__builtin_popcountll(balo), ncell += (uint32_t)__builtin_popcountll(bal);
+  }
+  if (nrec > (uint32_t)OL_REC || ncell > (uint32_t)OL_CELLS) return crowded();
+  __syncthreads();  // every occupant word has been read: the records may overwrite them
+  OL_STAMP(2);
+  // ---- 2b: the queued cells' records, one lane each ------------------------------------------------------------
+  const float t_out0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_out), 0));  // of 1.0: a set flag
+  if ((uint32_t)l < nrec) {
+    const int w = (int)L.work_w[l];
+    const uint32_t fl = L.work_fl[l];
+    int32_t cdmg = 0;
+    if (fl & SF_CELL_TEMP) {  // (a player-built object: on the map by construction)
+      const int i = r0 + w / SF_OBS_WINDOW, j = c0 + w % SF_OBS_WINDOW;
+      cdmg = gptr(p.aux_dmg)[(size_t)a * p.cells + (size_t)(f0 * p.N + i) * p.M + j];
+    }
+    uint32_t m = 0u;
+    obs_cell_emit(v, fl, cdmg, L.work_oc[l], pteam, [&](int k, float x) {
+      if (x == 0.f) return;
+      m |= 1u << k;
+      if (x == 1.f) {  // (Tables::obs_in[0] == 1.0: most of what a cell emits)
+        rec[l * OL_STRIDE + k] = t_out0;
+        return;
+      }
+      // raw value now; the table / x^(1/5) pass below maps every queued one densely
+      rec[l * OL_STRIDE + k] = x;
+      const uint32_t q = atomicAdd(&L.powq_n, 1u);
+      if (q < (uint32_t)OL_POWQ)
+        L.powq[q] = (uint16_t)(l * OL_STRIDE + k);
+      else
+        rec[l * OL_STRIDE + k] = obs_map(x);  // (obs_map of a table entry is the table's value up to the host's libm: never reached in practice)
+    });
+    L.recmask[l] = m;
+  }
+  __syncthreads();
+  OL_STAMP(3);
+  {
+    const uint32_t nq = L.powq_n < (uint32_t)OL_POWQ ? L.powq_n : (uint32_t)OL_POWQ;
+    for (uint32_t q = (uint32_t)l; q < nq; q += 64u) {
+      const uint32_t idx = L.powq[q];
+      const float x = rec[idx];
+      float y = 0.f;
+      bool fast = false;
+      for (int t = 1; t < t_n; ++t) {
+        const float ti = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_in), t));
+        const float to = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_out), t));
+        if (x == ti) y = to, fast = true;
+      }
+      rec[idx] = fast ? y : obs_map(x);
+    }
+  }
+  __syncthreads();
+  OL_STAMP(4);
+  // ---- 3: the list, in scan order: channel, then window cell ------------------------------------------------------
+  auto mask_of = [&](uint32_t s) { return s < (uint32_t)OBS_CLASS_RECS ? L.cmask[s] : L.recmask[s - OBS_CLASS_RECS]; };
+  auto value_of = [&](uint32_t s, uint32_t k) { return s < (uint32_t)OBS_CLASS_RECS ? L.crec[s][k] : rec[(s - OBS_CLASS_RECS) * OL_STRIDE + k]; };
+  // the compact cells, 64 per pass: which channels does a pass hold at all
+  constexpr int CP_MAX = OL_CELLS / 64;  // 10
+  const int npass = (int)((ncell + 63u) / 64u);
+  uint32_t cpm = 0u;  // lane i < npass: the OR of pass i's channel masks
+  for (int cp = 0; cp < npass; ++cp) {
+    const uint32_t c = (uint32_t)cp * 64u + (uint32_t)l;
+    const uint32_t m = c < ncell ? mask_of((uint32_t)L.cell[c] >> 10) : 0u;
+    const uint32_t o = wave_or(m);
+    cpm = l == cp ? o : cpm;
+  }
+  (void)CP_MAX;
+  OL_STAMP(5);
+  SF_GLOBAL uint32_t *kd = gptr(sp.keys) + (size_t)agent * (size_t)sp.cap;
+  SF_GLOBAL float *vd = gptr(sp.vals) + (size_t)agent * (size_t)sp.cap;
+  uint32_t base = 0u;
+  for (uint32_t k = 0; k < (uint32_t)SF_OBS_CHANNELS; ++k) {
+    uint32_t passes = (uint32_t)__builtin_amdgcn_ballot_w64(((cpm >> k) & 1u) != 0u);  // which passes hold channel k at all
+    while (passes) {
+      const int cp = __builtin_ctz(passes);
+      passes &= passes - 1u;
+      const uint32_t c = (uint32_t)cp * 64u + (uint32_t)l;
+      const uint32_t ent = c < ncell ? (uint32_t)L.cell[c] : 0u, s = ent >> 10, w = ent & 1023u;
+      const bool has = c < ncell && ((mask_of(s) >> k) & 1u) != 0u;
+      const uint64_t bal = __builtin_amdgcn_ballot_w64(has);
+      if (has) {
+        const uint32_t e = base + rank_below(bal);
+        if (e < (uint32_t)sp.cap) {
+          const uint32_t y = w / (uint32_t)SF_OBS_WINDOW, x = w - y * (uint32_t)SF_OBS_WINDOW;
+          kd[e] = (k * 9u) | (y << 9) | (x << 14), vd[e] = value_of(s, k);
+        }
+      }
+      base += (uint32_t)__builtin_popcountll(bal);
+    }
+  }
+  OL_STAMP(6);
+  if (l == 0) gptr(sp.counts)[agent] = base;
+  // the network's pov: cells (-1,0) (0,-1) (0,0) (0,1) (1,0) around the centre, channel fastest (Modules.hpp:114-121).
+  // Their compact entries first (wave-uniform, by ballot over the passes), then 160 lanes' worth of values
+  uint32_t pent[5] = {0xffffu, 0xffffu, 0xffffu, 0xffffu, 0xffffu};
+  for (int cp = 0; cp < npass; ++cp) {
+    const uint32_t c = (uint32_t)cp * 64u + (uint32_t)l;
+    const uint32_t ent = c < ncell ? (uint32_t)L.cell[c] : 0xffffu;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int dy = (q == 0) ? -1 : (q == 4) ? 1 : 0, dx = (q == 1) ? -1 : (q == 3) ? 1 : 0;
+      const uint32_t w = (uint32_t)((SF_OBS_WINDOW / 2 + dy) * SF_OBS_WINDOW + (SF_OBS_WINDOW / 2 + dx));
+      const uint64_t hit = __builtin_amdgcn_ballot_w64(c < ncell && (ent & 1023u) == w);
+      if (hit) pent[q] = (uint32_t)__builtin_amdgcn_readlane((int)ent, __builtin_ctzll(hit));
+    }
+  }
+  for (int t = l; t < 5 * SF_OBS_CHANNELS; t += 64) {
+    const int q = t >> 5, ch = t & 31;
+    const uint32_t ent = q == 0 ? pent[0] : q == 1 ? pent[1] : q == 2 ? pent[2] : q == 3 ? pent[3] : pent[4];
+    const uint32_t s = ent >> 10;
+    pov[t] = (ent != 0xffffu && ((mask_of(s) >> ch) & 1u)) ? value_of(s, (uint32_t)ch) : 0.f;
+  }
+  OL_STAMP(7);
+}
+
+__global__ __launch_bounds__(64) void k_observe_list(Params p, ObsSparse sp) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[OL_LDS_BYTES];
+  observe_list_wave(p, sp, (int)blockIdx.x, *reinterpret_cast<ObsListLds *>(lds));
+}
+
 #define SF_HIP(call)                                                                       \
   do {                                                                                     \
     hipError_t e_ = (call);                                                                \
@@ -668,6 +942,10 @@ struct HipRT {
   }
   int launch_observe_sparse(const Params &p, uint32_t *keys, float *vals, uint32_t *counts, float *pov, int cap) {
     SF_HIP(hipSetDevice(device));
+    static const bool old_form = getenv("SF_OBS_LIST_BLOCK") != nullptr;  // (A/B: the list as mode 3 of the dense kernel, round 3's form)
+    if (!old_form)
+      hipLaunchKernelGGL(k_observe_list, dim3((unsigned)(p.A * p.n_agents)), dim3(64), 0, stream, p, ObsSparse{keys, vals, counts, pov, cap});
+    else
     hipLaunchKernelGGL(k_observe, dim3((unsigned)(p.A * p.n_agents)), dim3(OBS_THREADS),
                        obs_lds_bytes(p),
                        stream, p, (float *)nullptr, (uint32_t *)nullptr, 3, ObsSparse{keys, vals, counts, pov, cap});
@@ -971,6 +1249,13 @@ int sf_comm_wait(sf_env *env, int32_t host_too) {
   if (host_too) SF_HIP(hipStreamSynchronize(c.side));
   return SF_OK;
 }
+#ifdef SF_DIAG_OBS
+int sf_diag_obs_read(sf_env *env, uint32_t *out, int32_t waves) {  // diagnostic build only: [waves][8] cycles of the last launch
+  SF_ENV(env);
+  if (env->e.rt.sync() != SF_OK) return SF_ERR_DEVICE;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sf::sf_diag_obs), (size_t)waves * 8 * sizeof(uint32_t)) == hipSuccess ? SF_OK : SF_ERR_DEVICE;
+}
+#endif
 #ifdef SF_DIAG_STAMPS
 int sf_diag_read(sf_env *env, uint32_t *out_host, int32_t arenas) {  // diagnostic build only (tools/diag_stamps.sh)
   SF_ENV(env);

@@ -159,7 +159,7 @@ inline int bm_words_for(int cells) { return ((cells + 31) / 32 + 3) & ~3; }  // 
 inline int nb_for(int B) { return (B + 63) / 64; }
 // Zombie or exit pools of more than 64 slots (the reference's hold 9000, gameplay.hpp:37,51-53) live in LDS instead of
 // one register lane per slot (Core<.., ZL>): [ZW_WORDS][64 * zombie words] + [64 * exit words] dwords behind the bitmaps
-inline bool large_pools(int Z, int P) { return Z > 64 || P > 64; }
+SF_HD inline bool large_pools(int Z, int P) { return Z > 64 || P > 64; }
 SF_HD inline int zw_for(int n) { return (n + 63) / 64; }  // 64-slot words of a table of n slots
 inline size_t zl_bytes_for(int Z, int P) {
   return large_pools(Z, P) ? 4u * 64u * ((size_t)ZW_WORDS * (size_t)zw_for(Z) + (size_t)zw_for(P)) : 0u;

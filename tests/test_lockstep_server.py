@@ -137,8 +137,10 @@ RECORDS = [config.HUMAN_ENEMY_TOKENS,
 
 def _check_records(worlds):
     first = worlds[0][0][0]  # humans of iteration 0 as player 0 sees them: (alive, f, r, c, way, team, hp, stamina, ...)
-    assert [h[6] for h in first[:3]] == [1000, 15000, 1000]          # Hp of the three records
-    assert [h[7] for h in first[:3]] == [1000000, 15000, 1000]       # stamina
+    # Hp and stamina of the three records — behind the first iteration, whose seed is the server's clock: somebody may
+    # already have been punched (Hp down by a few hundred) or have spent stamina on a shot (at most 50)
+    for h, hp, st in zip(first[:3], [1000, 15000, 1000], [1000000, 15000, 1000]):
+        assert hp - 800 < h[6] <= hp and st - 50 <= h[7] <= st, (h[6], h[7], hp, st)
 
 
 def test_three_clients_with_different_account_records():
