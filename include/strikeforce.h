@@ -33,7 +33,7 @@ extern "C" {
 
 /* Slot caps supported by the device kernels.  Humans: one wavefront lane each; bullets: four registers per lane.
  * Zombies and portal exits: the reference's own pool size (gameplay.hpp:37 `Z = 9000`, :51-53 `portal[B]`); pools of
- * more than 64 slots live in the arena's LDS (16 B per zombie slot, 4 B per exit) and sf_create refuses a
+ * more than 64 slots live in the arena's LDS (12 B per zombie slot, 4 B per exit) and sf_create refuses a
  * configuration whose flag plane and tables do not fit the CU's 160 KiB.  A whole Timer game of the reference on its
  * shipped maps holds at most 22 humans and 25 bullets at once (level 10, 37 500 steps), but 564 zombies and ~290 exits. */
 #define SF_MAX_HUMANS 64

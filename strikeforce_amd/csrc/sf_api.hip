@@ -697,8 +697,9 @@ static __device__ __forceinline__ void observe_list_wave(const Params &p, const 
   SF_GLOBAL uint32_t *kd = gptr(sp.keys) + (size_t)agent * (size_t)sp.cap;
   SF_GLOBAL float *vd = gptr(sp.vals) + (size_t)agent * (size_t)sp.cap;
   uint32_t base = 0u;
-  for (uint32_t k = 0; k < (uint32_t)SF_OBS_CHANNELS; ++k) {
-    uint32_t passes = (uint32_t)__builtin_amdgcn_ballot_w64(((cpm >> k) & 1u) != 0u);  // which passes hold channel k at all
+  for (uint32_t chans = wave_or(cpm); chans; chans &= chans - 1u) {  // the channels the window holds at all, ascending
+    const uint32_t k = (uint32_t)__builtin_ctz(chans);
+    uint32_t passes = (uint32_t)__builtin_amdgcn_ballot_w64(((cpm >> k) & 1u) != 0u);  // which passes hold channel k
     while (passes) {
       const int cp = __builtin_ctz(passes);
       passes &= passes - 1u;

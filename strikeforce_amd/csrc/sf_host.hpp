@@ -245,7 +245,7 @@ struct Env {
     p.npc_block = cfg.n_agent_profiles > 0 ? MAX_PROFILE_BLOCKS - 1 : 1;
     p.ht_bytes = ht_bytes_for(p.npc_block + 1), p.lds_tab = lds_tab_for(p.npc_block + 1);
     if (lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P) > rt.max_lds())
-      return fail(SF_ERR_ARG, large_pools(p.Z, p.P) ? "flag plane + zombie / exit tables (16 B per zombie slot, 4 B per exit) do not fit the CU's LDS: lower cap_zombies / cap_portals"
+      return fail(SF_ERR_ARG, large_pools(p.Z, p.P) ? "flag plane + zombie / exit tables (12 B per zombie slot, 4 B per exit) do not fit the CU's LDS: lower cap_zombies / cap_portals"
                                                    : "map does not fit the LDS flag plane");
     for (int i = 0; i < p.npc_block; ++i)
       derive_profile(cfg, (cfg.n_agent_profiles > 0 && i < cfg.n_agent_profiles) ? cfg.agent_profile[i] : cfg.player, tab.der[i]);
