@@ -60,13 +60,15 @@ def run_case(name):
     r = reftick.RefTick(w, player, native_caps=native_caps)
     o.reset((C.c_uint64 * 1)(tb), (C.c_uint64 * 1)(serial))
     r.reset(tb, serial)
-    cmds, _ = config.bench_commands(1, 1, steps, seed0=cmd_seed)
+    scripted = isinstance(cmd_seed, str)
+    if scripted:
+        cmds = np.frombuffer(cmd_seed.encode(), dtype=np.uint8).reshape(steps, 1, 1)
+    else:
+        cmds, _ = config.bench_commands(1, 1, steps, seed0=cmd_seed)
     digests, obs = [], {}
     for s in range(steps + 1):
         od, rd = o.dump(0), r.dump()
         assert not r.over, "%s step %d: the reference holds more entities than the configuration's pools" % (name, s)
-        if od.hdr.done:
-            break
         d = reftick.first_difference(rd, reftick.arrays_of(od))
         assert d is None, "%s step %d: %s" % (name, s, d)
         dg = digest_of(rd, od, w.cfg)
@@ -74,11 +76,15 @@ def run_case(name):
         digests.append("%016x" % dg)
         if s % ref_cases.OBS_EVERY == 0:
             obs[str(s)] = sparse(r.observe(0))
+        if od.hdr.done:  # (the state at the loop top that ended the game is the last one compared)
+            assert r.ended
+            break
         if s < steps:
             o.step(cmds[s])
             r.step(cmds[s, 0, :1])
     r.close()
-    return {"tb": tb, "serial": serial, "command_seed": cmd_seed, "reference_build": "native" if native_caps else "patched dimensions (gameplay.hpp:37)",
+    return {"tb": tb, "serial": serial, "command_seed": None if scripted else cmd_seed, "commands": cmd_seed if scripted else None,
+            "ended": bool(od.hdr.done), "outcome": int(od.hdr.outcome), "reference_build": "native" if native_caps else "patched dimensions (gameplay.hpp:37)",
             "digests": digests, "obs_nonzero": obs}
 
 

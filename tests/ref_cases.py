@@ -55,7 +55,14 @@ def plane(which, mode, player, level=1):
     return config.Workload("%s-dims" % which, cfg, m, p)
 
 
-# name -> (workload builder, player record, tb, serial, steps, command seed, native_caps)
+def squad_win_commands():
+    """The scripted Squad game that ends won (tests/tools/plan_squad_win.py wrote it): its header line and command string."""
+    with open(os.path.join(os.path.dirname(FIXTURE_MAP_DIR), "squad_win_commands.txt")) as f:
+        head, cmds = f.read().strip().split("\n")
+    return head, cmds
+
+
+# name -> (workload builder, player record, tb, serial, steps, command seed — or the command string itself —, native_caps)
 # native_caps True: the reference as it stands (3 x 30 x 100, pools of 9000); False: a patched-dimensions build
 # (gameplay.hpp:37 replaced) whose pools are exactly the configuration's
 GOLDEN_CASES = {
@@ -71,6 +78,9 @@ GOLDEN_CASES = {
     "shipped-timer-level3-full": (lambda: native(abi.MODE_TIMER, 3, RICH, maps="shipped"), RICH, 1700000999, 55555, 11250, 31, True),
     "shipped-squad-level3": (lambda: native(abi.MODE_SQUAD, 3, RICH, maps="shipped"), RICH,
                              1700004245, 424242, 600, 8, True),
+    # a Squad game played to its end, WON: ten team kills and every rival dead (gameplay.hpp:1204-1229), scripted
+    "shipped-squad-won": (lambda: native(abi.MODE_SQUAD, 1, RICH, maps="shipped"), RICH, 1700007777, 424242,
+                          len(squad_win_commands()[1]), squad_win_commands()[1], True),
     "C1": (lambda: baseline("C1", config.HUMAN_TOKENS), config.HUMAN_TOKENS, 1700000000, 123456789, 1000, 12345, False),
     "C2": (lambda: baseline("C2", config.HUMAN_ENEMY_TOKENS), config.HUMAN_ENEMY_TOKENS, 1700000002, 123456789, 1000, 12347, False),
     "C3": (lambda: baseline("C3", config.HUMAN_ENEMY_TOKENS), config.HUMAN_ENEMY_TOKENS, 1700000002, 123456789, 1000, 12347, False),

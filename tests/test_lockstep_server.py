@@ -252,6 +252,87 @@ def test_the_reference_client_and_two_of_ours_play_one_match():
         assert d is None, "iteration %d: %s" % (it, d)
 
 
+def test_a_configs4_shaped_battle_with_the_reference_client_in_it():
+    """BASELINE configs[4]'s shape — Battle Royale, 8 players, 256 x 256, pools H8 Z56 B128 — as a real match: the
+    reference's own client compiled for those dimensions (oracle/ref_tick.py TEST_DIMS; load_data's online branch places
+    the eight players on random '.' cells of the big map, gameplay.hpp:1846-1859) joins the reference's server in seat 3,
+    seven strikeforce_amd.lockstep clients take the other seats.  A shadow oracle in the reference client's seat, fed the
+    commands the match relayed, equals the reference client's whole world — 65 536 cells, every slot — after the
+    placement and after every one of 60 iterations."""
+    import reftick
+    if not reftick.available():
+        pytest.skip("oracle/_ref/sf_ref_tick not built")
+    from oracle_lib import Oracle
+    import ctypes as C
+    rich = [15000, 1000, 15000, 10, 10, 10, 300000, 60, 0, 0, 0, 1, 1, 1, 34] + [1] * 16 + [56]  # nobody dies in 60 iterations
+    n, seat, ticks = 8, 3, 60
+    teams = list(range(1, n + 1))
+    dims = dict(H=8, Z=56, B=128, P=128)  # (the reference pools exits by B, `portal[B]` gameplay.hpp:51-53)
+    port, password = _free_port(), "sesame"
+    proc = _start_server(port, password, teams)
+    m, portal = config.synthetic_map(256, 256, portal_pairs=2)
+    cfg0 = config.make_config(1, 256, 256, mode=abi.MODE_BATTLE, n_agents=n, teams=teams, auto_reset=0, player_tokens=rich, **dims)
+    ref = reftick.RefTick(config.Workload("match", cfg0, m, portal), rich, native_caps=False)
+    errors, ours, relayed, ref_dumps, ref_info = [], {}, {}, {}, {}
+
+    def ref_thread():
+        try:
+            tb, serial, ind, nn, team = ref.join_match("127.0.0.1", port, password)
+            ref_info.update(tb=tb, serial=serial, ind=ind, n=nn, team=team)
+            rng = np.random.RandomState(77)
+            ref_dumps[-1] = ref.dump()
+            for it in range(ticks):
+                ref.step(abi.BENCH_COMMANDS[rng.randint(0, 28)])
+                ref_dumps[it] = ref.dump()
+        except Exception as e:  # noqa: BLE001
+            errors.append(("reference client", repr(e)))
+
+    def our_thread(k):
+        try:
+            c = lockstep.MatchClient("127.0.0.1", port, password, rich, name="p%d" % k).connect()
+            sim = Oracle(c.workload(256, 256, m, portal, **dims))
+            ours[c.ind] = c
+            rng = np.random.RandomState(1000 + c.ind)
+            step0 = sim.step
+
+            def step(cmd):
+                relayed.setdefault(c.ind, []).append(bytes(cmd))
+                step0(cmd)
+            sim.step = step
+            lockstep.play(c, sim, lambda _s, _it: abi.BENCH_COMMANDS[rng.randint(0, 28)], max_iterations=ticks)
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=ref_thread) if k == seat else threading.Thread(target=our_thread, args=(k,)) for k in range(n)]
+    for t in threads:
+        t.start()
+        time.sleep(0.4)  # connection order = player index
+    for t in threads:
+        t.join(timeout=180)
+    ref.close()
+    try:
+        proc.stdin.write("done!\n")
+        proc.stdin.flush()
+        proc.wait(timeout=20)
+    except Exception:  # noqa: BLE001
+        proc.kill()
+    assert not errors, errors
+    assert (ref_info["ind"], ref_info["n"], ref_info["team"]) == (seat, n, teams[seat])
+    c0 = ours[0]
+    assert (c0.tb, c0.serial) == (ref_info["tb"], ref_info["serial"])
+    assert len(relayed[0]) == ticks and all(relayed[k] == relayed[0] for k in ours)
+    cfg = config.make_config(1, 256, 256, mode=abi.MODE_BATTLE, level=1, n_agents=n, teams=c0.teams, auto_reset=0,
+                             player_tokens=rich, ind=seat, agent_tokens=c0.records, **dims)
+    shadow = Oracle(config.Workload("shadow", cfg, m, portal))
+    shadow.reset((C.c_uint64 * 1)(c0.tb), (C.c_uint64 * 1)(c0.serial))
+    d = reftick.first_difference(ref_dumps[-1], reftick.arrays_of(shadow.dump(0)))
+    assert d is None, "after the placement: " + d
+    for it in range(ticks):
+        shadow.step(np.frombuffer(relayed[0][it], dtype=np.uint8))
+        d = reftick.first_difference(ref_dumps[it], reftick.arrays_of(shadow.dump(0)))
+        assert d is None, "iteration %d: %s" % (it, d)
+
+
 def test_the_reference_client_wins_the_match_when_both_rivals_have_quit():
     """check_end's online branch on the reference's own client (gameplay.hpp:1103-1119; kept in oracle/_ref/sf_ref_tick
     with only its end screen and key wait blanked, oracle/ref_tick.py): the two other players — strikeforce_amd.lockstep

@@ -8,6 +8,7 @@ one ended each way.  (The Timer mode's clock is time(0) - tb in the reference, g
 here: DESIGN §8; its end is not comparable under a fixed tb.  The online branch: tests/test_lockstep_server.py.)"""
 import ctypes as C
 
+import numpy as np
 import pytest
 
 import ref_cases
@@ -58,6 +59,39 @@ def test_solo_won_by_five_kills():
     humans and 24 zombies), level 1: the fifth kill ends the game at step 2346 — not one loop top earlier."""
     steps, hdr = play_to_the_end(solo("C3", ref_cases.RICH), ref_cases.RICH, 1700000220, 720, 2400)
     assert (steps, hdr.outcome, hdr.kills) == (2346, abi.WON, 5)
+
+
+def test_squad_won_by_ten_team_kills_and_dead_rivals():
+    """`level * 10 <= teams_kills && rivals_are_dead() && mode == "Squad"` (gameplay.hpp:1204-1229) on the reference's own
+    function, on its shipped maps: the scripted game of tests/golden/squad_win_commands.txt (tests/tools/plan_squad_win.py:
+    through the entrances of floors 1 and 2 to the five opponents on floor 3, a punch each, then whatever comes near).
+    The reference's check_end() says "go on" at every loop top before — also at the one behind the fifth opponent's
+    death, with `rivals_are_dead()` true and teams_kills short of ten — and "won" at the loop top behind the tenth kill."""
+    head, cmds = ref_cases.squad_win_commands()
+    w = ref_cases.native(abi.MODE_SQUAD, 1, ref_cases.RICH, maps="shipped")
+    o = Oracle(w)
+    r = reftick.RefTick(w, ref_cases.RICH)
+    try:
+        o.reset((C.c_uint64 * 1)(1700007777), (C.c_uint64 * 1)(424242))
+        r.reset(1700007777, 424242)
+        rivals_dead_at = None
+        for s, ch in enumerate(cmds):
+            o.step(np.array([ord(ch)], dtype=np.uint8))
+            r.step(ch)
+            od, rd = o.dump(0), r.dump()
+            assert not r.over
+            d = reftick.first_difference(rd, reftick.arrays_of(od))
+            assert d is None, "step %d: %s" % (s, d)
+            assert r.ended == bool(od.hdr.done), "step %d: the reference's check_end() says %s, ours %s" % (s, r.ended, od.hdr.done)
+            if rivals_dead_at is None and r.rivals_are_dead():
+                rivals_dead_at = (s, od.hdr.teams_kills)
+            if od.hdr.done:
+                break
+        assert s == len(cmds) - 1 and od.hdr.outcome == abi.WON and od.hdr.teams_kills == 10
+        assert rivals_dead_at is not None and rivals_dead_at[0] < s and rivals_dead_at[1] < 10, rivals_dead_at
+    finally:
+        r.close()
+        o.close()
 
 
 @pytest.mark.parametrize("which,player,tb,seed,steps", [("C2", config.HUMAN_ENEMY_TOKENS, 1700000108, 508, 147),

@@ -40,8 +40,12 @@ def test_reproduces_the_references_trajectory(name, impl, ulp_tol):
     sim.reset((C.c_uint64 * 1)(gold["tb"]), (C.c_uint64 * 1)(gold["serial"]))
     digests = gold["digests"]
     steps = len(digests) - 1
-    assert steps >= 400
-    cmds, _ = config.bench_commands(1, 1, steps, seed0=gold["command_seed"])
+    if gold.get("commands"):  # a scripted game (the Squad game played to its end)
+        assert steps >= 200 and len(gold["commands"]) >= steps
+        cmds = np.frombuffer(gold["commands"].encode(), dtype=np.uint8).reshape(-1, 1, 1)
+    else:
+        assert steps >= 400
+        cmds, _ = config.bench_commands(1, 1, steps, seed0=gold["command_seed"])
     for s in range(steps + 1):
         assert "%016x" % int(sim.digest()[0]) == digests[s], "%s: state after %d steps differs from the reference's" % (name, s)
         if str(s) in gold["obs_nonzero"]:
@@ -54,6 +58,8 @@ def test_reproduces_the_references_trajectory(name, impl, ulp_tol):
             assert ulp <= ulp_tol, "%s: observation after %d steps differs from the reference's by %d ulp" % (name, s, ulp)
         if s < steps:
             sim.step(cmds[s])
+    if gold.get("ended"):  # the reference's own check_end() ended the game here; so must ours, the same way
+        assert bool(sim.done()[0]) and int(sim.results()[0, 0, 7]) == gold["outcome"]
 
 
 @pytest.mark.parametrize("impl,ulp_tol", IMPLS)
