@@ -276,6 +276,10 @@ def main():
     backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
     local = int(os.environ.get("SF_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
+    # Everything runs on a stream of its own, made torch's current stream (the HIP events below — torch's and the
+    # library's — are recorded on it): launches on the NULL stream pay its implicit ordering against every other stream,
+    # ~10 % on the one-launch-per-step loops (tools/r04_two_streams.py: 52 M against 44-48 M env-steps/s)
+    torch.cuda.set_stream(torch.cuda.Stream())
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("gloo")
@@ -482,11 +486,15 @@ def main():
 
         closed_loop(2)
         torch.cuda.synchronize()
-        pb.kernel_time(True)
+        # the loop's rate first, with nothing but the two events around it; then once more with the library's per-launch
+        # events on (two hipEventRecord per matrix launch: ~8 % of a loop of this length) for the per-kernel rows
         pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         pe[0].record()
         closed_loop(pol_n)
         pe[1].record()
+        torch.cuda.synchronize()
+        pb.kernel_time(True)
+        closed_loop(pol_n)
         torch.cuda.synchronize()
         by_k = pb.kernel_time_by_kernel(False)  # k_gemm (f32), k_gemm_b3 (bf16 split), conv0 on the non-zeros, k_tail
         sp_over = pb.sparse_overflows()

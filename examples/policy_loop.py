@@ -18,9 +18,14 @@ arenas = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 w = config.baseline_workload("C2", arenas=arenas)           # 64x64 map, 1 player + 16 zombies, auto-reset
 sim = env.ArenaBatch(w)
-sim.reset(*w.seeds())
 agents = arenas * w.cfg.n_agents
 net = policy.PolicyBatch(policy.init_parameters(seed=0), agents)
+# a stream of its own for both libraries: launches on the NULL stream pay its implicit ordering against every other stream
+# (~10 % on a loop of one launch per step)
+stream = torch.cuda.Stream()
+torch.cuda.set_stream(stream)
+sim.set_stream(stream.cuda_stream), net.set_stream(stream.cuda_stream)
+sim.reset(*w.seeds())
 d_obs = torch.empty((agents, 32, 31, 31), dtype=torch.float32, device="cuda")
 d_probs = torch.empty((agents, 9), dtype=torch.float32, device="cuda")
 d_value = torch.empty(agents, dtype=torch.float32, device="cuda")

@@ -1395,8 +1395,23 @@ __device__ __forceinline__ void tail_barrier() {
 #endif
 }
 
+#ifdef SF_DIAG_TAIL  // diagnostic build only (tools/r04_tail_stamps.py): cycles per phase of k_tail, per wave of the last launch
+__device__ uint32_t sf_diag_tail[4096 * 16 * 24];  // [workgroup][wave][phase]
+#define TL_STAMP(ph)                                                                                         \
+  do {                                                                                                       \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                              \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096u)                                                       \
+      sf_diag_tail[(blockIdx.x * 16u + (threadIdx.x >> 6)) * 24u + (ph)] = (uint32_t)(t_ - tl_last_);        \
+    tl_last_ = t_;                                                                                           \
+  } while (0)
+#else
+#define TL_STAMP(ph)
+#endif
 __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
   extern __shared__ __attribute__((aligned(16))) float tl[];
+#ifdef SF_DIAG_TAIL
+  unsigned long long tl_last_ = __builtin_amdgcn_s_memtime();
+#endif
   // (readfirstlane: the wave index is uniform, and the compiler should know — tile choices become scalar branches)
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = threadIdx.x & 63;
   const int a_raw = blockIdx.x * TL_R + w;
@@ -1446,7 +1461,9 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     return ts_wp(t.res_w[hd][i], HID, n0, l);
   };
   if (t.feat) b0 = ts_issue<5>(b0, gru_wp(0, w), 0);  // (folded form: gru0's first tile is this wave's first)
+  TL_STAMP(0);
   tail_barrier();
+  TL_STAMP(1);
   if (t.feat) {
     row_store(tl + TL_Y0 + w * TL_LD, l, row_load(t.feat + (size_t)a * HID, l));
   } else {
@@ -1455,7 +1472,9 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
   }
   tail_barrier();
   row_store(tl + TL_B0 + w * TL_LD, l, row_norm(row_load(tl + TL_Y0 + w * TL_LD, l)));  // feat_n :108
+  TL_STAMP(2);
   tail_barrier();
+  TL_STAMP(3);
   // ---- gru0: gi = W_ih feat_n + b_ih, gh = W_hh h0 + b_hh (30 + 30 tiles)                          :110-113
   for (int tt = w; tt < 2 * (G3 / 16); tt += TL_R) {
     const int hh = tt >= G3 / 16, n0 = 16 * (tt - hh * (G3 / 16));
@@ -1466,7 +1485,9 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
                  return ts_issue<5>(b, gru_wp(1, w), 0);                                            // (no tile there: gru1)
                });
   }
+  TL_STAMP(4);
   tail_barrier();
+  TL_STAMP(5);
   {  // gru cell, combined = [norm(h0') + feat_n | norm(pov) | 0]                                        :110-123
     const Row3 hn = gru_cell(tl + TL_GI + w * G3, tl + TL_GH + w * G3, row_load(tl + TL_B1 + w * TL_LD, l), l);
     if (valid) row_store(t.h[0] + (size_t)a * HID, l, hn);
@@ -1492,13 +1513,19 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     }
     row_store(tl + TL_B1 + w * TL_LD, l, row_load(tl + TL_H1 + w * TL_LD, l));  // h1 takes h0's place
   }
+  TL_STAMP(6);
   tail_barrier();
+  TL_STAMP(7);
   if (w < HID / 16)                                                                                         // :125
     ts_tile352(tl + TL_COMB, TL_LDC, ts_wp(t.comb_w, COMB_PAD, 16 * w, l), t.comb_b, tl + TL_Y0, TL_LD, 16 * w, l, b0, b1,
                [&](TsBuf b) { return ts_issue<5>(b, gru_wp(1, w), 0); });
+  TL_STAMP(8);
   tail_barrier();
+  TL_STAMP(9);
   row_store(tl + TL_B2 + w * TL_LD, l, row_norm(row_load(tl + TL_Y0 + w * TL_LD, l)));  // gated_n :126
+  TL_STAMP(10);
   tail_barrier();
+  TL_STAMP(11);
   for (int tt = w; tt < 2 * (G3 / 16); tt += TL_R) {  // gru1                                             :128-131
     const int hh = tt >= G3 / 16, n0 = 16 * (tt - hh * (G3 / 16));
     ts_tile160(tl + (hh ? TL_B1 : TL_B2), TL_LD, gru_wp(1, tt), hh ? t.gru_b_hh[1] : t.gru_b_ih[1], tl + (hh ? TL_GH : TL_GI), G3, n0, l,
@@ -1507,7 +1534,9 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
                  return ts_issue<5>(b, res_wp(0, w), 0);  // next: the first ResB layer
                });
   }
+  TL_STAMP(12);
   tail_barrier();
+  TL_STAMP(13);
   {  // out = norm(h1') + gated_n; both heads start from norm(out)
     const Row3 hn = gru_cell(tl + TL_GI + w * G3, tl + TL_GH + w * G3, row_load(tl + TL_B1 + w * TL_LD, l), l);
     if (valid) row_store(t.h[1] + (size_t)a * HID, l, hn);
@@ -1519,7 +1548,9 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     row_store(tl + TL_X0 + w * TL_LD, l, xn);
     row_store(tl + TL_X1 + w * TL_LD, l, xn);
   }
+  TL_STAMP(14);
   tail_barrier();
+  TL_STAMP(15);
   for (int i = 0; i < 3; ++i) {  // ResB layers of the two heads                                           :41-48
     for (int tt = w; tt < 2 * (HID / 16); tt += TL_R) {
       const int hd = tt >= HID / 16, n0 = 16 * (tt - hd * (HID / 16));
@@ -1531,7 +1562,9 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
                    return b;
                  });
     }
+    TL_STAMP(16);
     tail_barrier();
+    TL_STAMP(17);
 #pragma unroll
     for (int hd = 0; hd < 2; ++hd) {
       float *xp = tl + (hd ? TL_X1 : TL_X0) + w * TL_LD;
@@ -1541,14 +1574,18 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
       for (int q = 0; q < 3; ++q) r.v[q] = fmaxf(y.v[q], 0.f) + xv.v[q];
       row_store(xp, l, row_norm(r));
     }
+    TL_STAMP(18);
     tail_barrier();
+    TL_STAMP(19);
   }
   // p = softmax(W_p x_p + b_p) + 1e-8, v = sigmoid(W_v x_v + b_v)                                           :172-175
   // (the two output layers as one MFMA tile each: weights padded with zero rows to 16 columns)
   if (w < 2)
     ts_tile160(tl + (w ? TL_X1 : TL_X0), TL_LD, ts_wp(t.head_w[w], HID, 0, l), t.head_b[w], tl + (w ? TL_LIN1 : TL_LIN0), TL_LD, 0, l, b0, b1,
                [&](TsBuf b) { return b; });
+  TL_STAMP(20);
   tail_barrier();
+  TL_STAMP(21);
   if (valid) {
     const float *lg = tl + TL_LIN0 + w * TL_LD;
     float mx = lg[0];
@@ -1564,6 +1601,7 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     if (l < ACT) t.probs[(size_t)a * ACT + l] = mine / s + 1e-8f;
     if (l == 0) t.value[a] = sigmoidf_(tl[TL_LIN1 + w * TL_LD]);
   }
+  TL_STAMP(22);
 }
 
 __global__ void k_reset_memory(float *h0, float *h1, float *action_input, const uint8_t *mask, int agents) {
@@ -2143,6 +2181,12 @@ int sf_policy_forward_sparse_or_dense(sf_policy *pp, const uint32_t *d_keys, con
   return sfp::forward(p, d_dense, agents, d_probs, d_value, &li, d_pov);
 }
 
+#ifdef SF_DIAG_TAIL
+int sf_policy_diag_tail_read(uint32_t *out, int32_t workgroups) {  // diagnostic build only: [workgroups][16 waves][24 phases] cycles
+  if (hipDeviceSynchronize() != hipSuccess) return SF_ERR_DEVICE;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sfp::sf_diag_tail), (size_t)workgroups * 16 * 24 * sizeof(uint32_t)) == hipSuccess ? SF_OK : SF_ERR_DEVICE;
+}
+#endif
 int sf_policy_sparse_overflows(sf_policy *pp, int32_t *count) {
   Policy *p = reinterpret_cast<Policy *>(pp);
   if (!p || !count) return sfp::fail(SF_ERR_ARG, "null argument");
