@@ -252,6 +252,11 @@ def baseline_workload(which, arenas=None, device=0, auto_reset=1):
         cfg = make_config(arenas or 2, 30, 100, floors=3, H=64, Z=64, B=256, P=32, mode=abi.MODE_SOLO, level=2,
                           device=device, auto_reset=auto_reset)
         m, p = three_floor_map(30, 100, wall_p=0.06, map_seed=11)
+    elif which == "NATIVEGAME":  # a whole game on the reference's own dimensions: Timer level 3 (11 250 steps), pools of 1024
+        # zombies and 512 exits — more than 64 slots: the device keeps those tables in LDS (sf_core.hpp ZL)
+        cfg = make_config(arenas or 2, 30, 100, floors=3, H=64, Z=1024, B=256, P=512, mode=abi.MODE_TIMER, level=3,
+                          device=device, auto_reset=auto_reset)
+        m, p = three_floor_map(30, 100, wall_p=0.06, map_seed=11)
     elif which == "STRESS":  # not a BASELINE config: tiny slot pools so that every allocator runs dry
         cfg = make_config(arenas or 8, 24, 40, H=6, Z=12, B=5, P=3, chests=6, mode=abi.MODE_TIMER, device=device,
                           auto_reset=auto_reset, timer_frames=600)

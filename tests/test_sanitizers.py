@@ -24,6 +24,17 @@ for name, arenas, steps in (("C3", 3, 250), ("STRESS", 4, 400), ("MAXCAP", 2, 80
     e.step_many(cmds)
     e.observe()
     e.digest()
+# large pools (zombie / exit tables in the emulated LDS, sf_core.hpp ZL): every kernel variant, far enough for three words of
+# zombies and two of exits, with a restart on the way (tests/test_large_pools.py's worlds)
+import test_large_pools
+for n in (64, 120, 160):
+    w = test_large_pools.world(n, 2)
+    e = Emu(w, asan=True)
+    e.reset(*w.seeds())
+    cmds, _ = config.bench_commands(2, 1, 4700, seed0=4321)
+    e.step_many(cmds)
+    e.observe()
+    e.digest()
 print("SANITIZED-OK")
 """
 
