@@ -53,6 +53,41 @@ def test_the_list_is_the_dense_observation(which):
     assert np.array_equal(pv.view(np.uint32), want.view(np.uint32))
 
 
+def test_the_list_is_the_dense_observation_with_large_pools():
+    """Zombie and exit tables of more than 64 slots (in LDS for the step kernels, read where they lie by both observation
+    kernels): 4600 steps into tests/test_large_pools.py's world, ~140 zombies in three 64-slot words and ~100 exits.  Every
+    agent's list equals its dense observation; a window with more than 48 occupied cells says "crowded" instead."""
+    import test_large_pools
+    w = test_large_pools.world(64, 12)
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    B = w.cfg.arenas
+    cmds, _ = config.bench_commands(B, 1, 4600, seed0=4321)
+    d = torch.from_numpy(np.ascontiguousarray(cmds)).cuda()
+    g.step_device(d.data_ptr(), 4600)
+    d_obs = torch.zeros((B, 32, 31, 31), dtype=torch.float32, device="cuda")
+    keys, vals, counts, pov = _bufs(B)
+    g.observe_device(d_obs.data_ptr())
+    g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP)
+    g.synchronize()
+    assert max(sum(z.alive for z in g.dump(a).zombies) for a in range(B)) > 128
+    obs = d_obs.cpu().numpy().reshape(B, -1)
+    k, v, n = keys.cpu().numpy().view(np.uint32), vals.cpu().numpy(), counts.cpu().numpy().view(np.uint32)
+    compared = 0
+    for a in range(B):
+        nz = np.flatnonzero(obs[a])
+        if n[a] == 0xFFFFFFFF:
+            assert len(np.unique(nz % 961)) > 48  # (more occupied cells than the list kernel has records)
+            continue
+        assert n[a] == len(nz) and n[a] > 100
+        ch, r = np.divmod(nz, 961)
+        y, x = np.divmod(r, 31)
+        assert np.array_equal(k[a, :n[a]], (ch * 9) | (y << 9) | (x << 14))
+        assert np.array_equal(v[a, :n[a]].view(np.uint32), obs[a][nz].view(np.uint32))
+        compared += 1
+    assert compared >= B // 2
+
+
 def test_sparse_and_dense_forward_are_bit_identical(cnn):
     w = config.baseline_workload("C3", arenas=40)
     g = env.ArenaBatch(w)
