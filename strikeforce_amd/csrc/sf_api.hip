@@ -475,7 +475,7 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
 // ---- sf_observe_sparse_device: the observation as the list of its non-zero floats, one WAVEFRONT per (arena, agent) ----
 // The dense kernel above is built around streaming 123 KB per agent; for the list form that stream does not exist and
 // what is left — 16 384 wavefronts for 4096 agents, five workgroup barriers around a few hundred useful operations per
-// thread — costs the launch ramp of those wavefronts (~4.5 ns each: 0.075 ms, round 3).  Here one 64-lane wavefront does
+// thread — takes 0.075 ms (round 3).  Here one 64-lane wavefront does
 // the whole window, without workgroup barriers:
 //   0  the window's 961 flag bytes are requested first, all sixteen loads of a lane in flight at once
 //   1  every entity of the arena scatters itself into the window's occupant words (LDS atomics)
@@ -843,8 +843,17 @@ struct HipRT {
 
   template <int NB, bool ZL>
   int do_step(const Params &p, const uint8_t *cmds, int k) {
-    const bool hp = hbm_plane(p.cells_pad), bm = use_bitmaps(p.cells_pad);
-    const size_t lds = lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P);
+    // SF_HBM_PLANE_K_MAX=k (A/B switch, default 0 = off): launches of at most k steps leave the flag plane in HBM (the
+    // HBM-plane variant, whatever the map's size) instead of staging it — 8 KB less HBM traffic per arena of a one-step
+    // launch of configs[2] (of 14), and measured slower: 0.0817 -> 0.0859 ms per step of the interactive loop, the step's
+    // own cell reads then pay L2 latency one by one (tools/experiments/README.md)
+    static const int hp_k_max = [] {
+      const char *e = getenv("SF_HBM_PLANE_K_MAX");
+      return e ? atoi(e) : 0;
+    }();
+    const bool hp = hbm_plane(p.cells_pad) || k <= hp_k_max, bm = use_bitmaps(p.cells_pad);
+    const size_t lds = hbm_plane(p.cells_pad) || !hp ? lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P)
+                                                     : lds_bytes_for(p.cells_pad, p.lds_tab, p.Z, p.P) - (size_t)p.cells_pad;
     int rc = !hp ? lds_attr(k_step<NB, false, true, ZL>, lds) : bm ? lds_attr(k_step<NB, true, true, ZL>, lds) : lds_attr(k_step<NB, true, false, ZL>, lds);
     if (rc) return rc;
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
