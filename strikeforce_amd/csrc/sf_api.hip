@@ -27,6 +27,7 @@ namespace sf {
 
 #ifdef SF_DIAG_STAMPS
 __device__ uint32_t sf_diag_buffer[16 * 65536];  // diagnostic build only: [arena][phase] wave cycles of the last launch
+__device__ unsigned long long sf_diag_times[4 * 65536];  // [workgroup]: s_memrealtime (100 MHz) at the wave's start, after load(), before store(), at its end
 #endif
 
 // HP (HBM_PLANE): maps whose flag plane is too large for LDS keep it in HBM (sf_core.hpp).  BM (BITMAPS): the cell
@@ -42,7 +43,14 @@ template <int NB, bool HP, bool BM, bool ZL>
 __global__ __launch_bounds__(64) void k_step(Params p, const uint8_t *cmds, int k) {
   extern __shared__ __attribute__((aligned(2048))) uint8_t lds[];  // the RNG power table comes first (W::pow_pair)
   const int a = p.perm ? (int)gptr(p.perm)[blockIdx.x] : (int)blockIdx.x;
+#ifdef SF_DIAG_STAMPS
+  if (threadIdx.x == 0) sf_diag_times[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
   Core<WaveGfx950, NB, HP, BM, ZL>::step_body(lds, p, a, cmds, k);
+#ifdef SF_DIAG_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);  // (the stores have left)
+  if (threadIdx.x == 0) sf_diag_times[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Launch order for k_step: arenas by population (live zombies + live humans as the last store() recorded them, SC_LOAD),
@@ -1267,6 +1275,12 @@ int sf_diag_obs_read(sf_env *env, uint32_t *out, int32_t waves) {  // diagnostic
 }
 #endif
 #ifdef SF_DIAG_STAMPS
+int sf_diag_times_read(sf_env *env, unsigned long long *out_host, int32_t workgroups) {  // diagnostic build only (tools/r04_k1_times.py)
+  SF_ENV(env);
+  if (env->e.rt.sync() != SF_OK) return SF_ERR_DEVICE;
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(sf::sf_diag_times), (size_t)workgroups * 4 * sizeof(unsigned long long)) == hipSuccess
+             ? SF_OK : SF_ERR_DEVICE;
+}
 int sf_diag_read(sf_env *env, uint32_t *out_host, int32_t arenas) {  // diagnostic build only (tools/diag_stamps.sh)
   SF_ENV(env);
   if (env->e.rt.sync() != SF_OK) return SF_ERR_DEVICE;

@@ -2107,6 +2107,7 @@ struct Core {
     // 16 is the best for long launches (+1.7 % over 4) and for one-step launches (p90 128 -> 28 us).
     S.wrate = 4u;
     S.ended = 0;
+    SF_STAMP_LOADED();
     SF_STAMP_BEGIN(S);
     for (int s = 0; s < k; ++s) {
       const uint8_t *c = cmds + ((size_t)s * (size_t)p.A + (size_t)a) * (size_t)p.n_agents;
@@ -2114,6 +2115,7 @@ struct Core {
       step(S, lds, p, a);
     }
     SF_STAMP_END(S, a);
+    SF_STAMP_STEPPED();
     store(S, lds, p, a);
   }
 

@@ -196,6 +196,7 @@ struct Env {
   uint8_t *d_cmd = nullptr;
   uint32_t *d_perm = nullptr;  // k_step's launch order (k_rank): arenas by population, for long launches
   int balance = 1;             // SF_BALANCE=0 switches the ordering off (A/B measurements)
+  int rank_k_min = 8;          // launches of fewer steps run in arena order
   int steps_since_rank = 1 << 30;  // the order is renewed every >= 100 steps (populations change by one every 20-25 steps)
   float *d_obs = nullptr;
   uint32_t *d_nzprev = nullptr;      // [A * n_agents][961] which floats of the delta-tracked buffer are non-zero
@@ -239,6 +240,8 @@ struct Env {
     {
       const char *e = getenv("SF_BALANCE");  // (A/B measurements: SF_BALANCE=0 switches k_rank's launch order off)
       balance = (e && e[0] == '0') ? 0 : 1;
+      const char *r = getenv("SF_RANK_K_MIN");  // (A/B measurements: the shortest launch that is ordered)
+      if (r) rank_k_min = atoi(r);
     }
     // tables: one shared player record (block 0) + npc (block 1), or one record per commanded human (blocks 0..15,
     // the account blobs of a lock-step match, gameplay.hpp:120-151) + npc (block 16)
@@ -389,7 +392,7 @@ struct Env {
     // 16384 arenas, an arena count that is no multiple of 1024, and the maps whose flag plane stays in HBM
     // (profiles/r04b_rank_sweep.txt): +1 % (2048) ... +14 % (5000) on configs[2], +4 % on configs[4], -0.6 % on configs[3]
     // (every arena at its caps: nothing to order, k_rank's 7 us per 100 steps is what is left)
-    if (balance && k >= 8 && p.A >= 1024 && rt.can_rank()) {
+    if (balance && k >= rank_k_min && p.A >= 1024 && rt.can_rank()) {
       int rc;
       if (!d_perm && (rc = alloc(d_perm, (size_t)p.A))) return rc;
       if (steps_since_rank >= 100) {

@@ -50,10 +50,23 @@ extern __device__ uint32_t sf_diag_buffer[];
   do {                     \
     if (threadIdx.x < 16u) ::sf::sf_diag_buffer[(size_t)(a) * 16u + threadIdx.x] = (S).dacc; \
   } while (0)
+// absolute times (100 MHz) of a k_step wave: state loaded, steps done (sf_api.hip sf_diag_times; tools/r04_k1_times.py)
+extern __device__ unsigned long long sf_diag_times[];
+#define SF_STAMP_LOADED()                                                                    \
+  do {                                                                                       \
+    __builtin_amdgcn_s_waitcnt(0);                                                           \
+    if (threadIdx.x == 0) ::sf::sf_diag_times[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define SF_STAMP_STEPPED()                                                                   \
+  do {                                                                                       \
+    if (threadIdx.x == 0) ::sf::sf_diag_times[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define SF_STAMP_BEGIN(S)
 #define SF_STAMP(S, ph)
 #define SF_STAMP_END(S, a)
+#define SF_STAMP_LOADED()
+#define SF_STAMP_STEPPED()
 #endif
 
 #ifndef SF_RNG_PRIO

@@ -45,6 +45,8 @@ struct EmuProfScope {
 #define SF_STAMP_BEGIN(S)  // in-kernel phase stamps exist only in the device's diagnostic build
 #define SF_STAMP(S, ph)
 #define SF_STAMP_END(S, a)
+#define SF_STAMP_LOADED()
+#define SF_STAMP_STEPPED()
 #define EMU_OP() (++::sf::emu_prof().ops)
 #define EMU_SOP() (++::sf::emu_prof().sops)
 
