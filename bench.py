@@ -397,7 +397,7 @@ def main():
 
     # the interactive loop an RL learner runs: one launch per step (K = 1) + the observation of every agent
     obs_n = 0 if args.no_interactive else 40
-    loop_ms = obs_ms = k1_ms = host_ms = loop_delta_ms = loop_sparse_ms = 0.0
+    loop_ms = obs_ms = k1_ms = host_ms = loop_delta_ms = loop_sparse_ms = loop_halves_ms = 0.0
     if obs_n:
         d_obs = torch.empty(args.arenas * cfg.n_agents * 30752, dtype=torch.float32, device="cuda")
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
@@ -446,6 +446,46 @@ def main():
             g.step(cmds[s % total])
         g.synchronize()
         host_ms = (time.perf_counter() - t1) * 1e3 / obs_n
+        # The same list-observation loop driven as TWO half-batches on two streams: a one-step launch ends with the
+        # youngest waves of its SIMDs (tools/experiments/README.md, the timeline of a one-step launch); the other half's
+        # kernels fill that tail.  Same arenas, same seeds, same commands as the one batch, brought to the same point
+        # of their games first.
+        halves = []
+        if args.arenas % 2 == 0:
+            done_steps = pre + args.warmup + args.steps * len(dts)
+            for j in range(2):
+                n = args.arenas // 2
+                wj = config.baseline_workload(args.workload, arenas=n, device=local)
+                wj.cfg.reseed_stride = world * args.arenas
+                gj = env.ArenaBatch(wj)
+                sj = torch.cuda.Stream()
+                gj.set_stream(sj.cuda_stream)
+                gj.reset(*wj.seeds(first_arena=rank * args.arenas + j * n))
+                cj, _ = config.bench_commands(n, cfg.n_agents, done_steps + 2 * obs_n, seed0=shard.command_seed(w, rank) + j * n * cfg.n_agents)
+                with torch.cuda.stream(sj):
+                    dj = torch.from_numpy(cj).cuda()
+                    bj = (torch.zeros((n * cfg.n_agents, 2048), dtype=torch.int32, device="cuda"),
+                          torch.zeros((n * cfg.n_agents, 2048), dtype=torch.float32, device="cuda"),
+                          torch.zeros(n * cfg.n_agents, dtype=torch.int32, device="cuda"), torch.zeros((n * cfg.n_agents, 160), device="cuda"))
+                sj.synchronize()
+                for s0 in range(0, done_steps, args.k_per_launch):
+                    gj.step_device(dj.data_ptr() + s0 * n * cfg.n_agents, min(args.k_per_launch, done_steps - s0))
+                halves.append((gj, n * cfg.n_agents, dj, bj))
+
+            def half_loop(first, count):
+                for s in range(first, first + count):
+                    for gj, sn, dj, bj in halves:
+                        gj.step_device(dj.data_ptr() + s * sn, 1)
+                        gj.observe_sparse_device(bj[0].data_ptr(), bj[1].data_ptr(), bj[2].data_ptr(), bj[3].data_ptr(), 2048)
+            half_loop(done_steps, 5)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            half_loop(done_steps + 5, obs_n)
+            torch.cuda.synchronize()
+            loop_halves_ms = (time.perf_counter() - t1) * 1e3 / obs_n
+            for gj, _sn, _dj, _bj in halves:
+                gj.close()
+            del halves
     g.kernel_time(False)
 
     # the closed loop with the reference's bot network evaluated on the device:
@@ -609,7 +649,11 @@ def main():
               "sparse_observation": {"what": "same loop with sf_observe_sparse_device (the non-zero floats as a list, the form "
                                              "sf_policy_forward_sparse takes; no dense buffer)",
                                      "env_steps_per_s": world * args.arenas / (loop_sparse_ms / 1e3),
-                                     "ms_per_step": loop_sparse_ms},
+                                     "ms_per_step": loop_sparse_ms,
+                                     "two_half_batches": None if not loop_halves_ms else {
+                                         "what": "the same arenas as two half-batches (two sf_env, two streams): each half's one-step "
+                                                 "launches fill the other's tails; wall clock over %d steps" % obs_n,
+                                         "env_steps_per_s": world * args.arenas / (loop_halves_ms / 1e3), "ms_per_step": loop_halves_ms}},
             "sf_step_host_cmd_ms": host_ms,
               "k_observe_roofline": {"bound": "hbm", "achieved": obs_bytes / (obs_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": obs_bytes / (obs_ms / 1e3) / 1e9 / HBM_PEAK_GBS,

@@ -7,8 +7,10 @@ for f in sys.argv[1:]:
     line = "%s value %.1f M frac %.3f" % (f, d["value"] / 1e6, d["roofline"]["frac"])
     if "interactive" in d:
         i = d["interactive"]
-        line += " | interactive dense %.1f delta %.1f list %.1f M (K=1 step %.4f ms, k_observe %.4f ms)" % (
+        hb = i["sparse_observation"].get("two_half_batches")
+        line += " | interactive dense %.1f delta %.1f list %.1f M (two halves %s M; K=1 step %.4f ms, k_observe %.4f ms)" % (
             i["env_steps_per_s"] / 1e6, i["delta_observation"]["env_steps_per_s"] / 1e6, i["sparse_observation"]["env_steps_per_s"] / 1e6,
+            ("%.1f" % (hb["env_steps_per_s"] / 1e6)) if hb else "-",
             i["k_step_K1_ms"], i["k_observe_ms"])
     if "policy" in d:
         p = d["policy"]
