@@ -511,12 +511,23 @@ def main():
         # at once): nobody is ever evaluated on a blank window, and nothing synchronises with the host
         d_fallback = torch.empty((agents, 30752), dtype=torch.float32, device="cuda")
 
-        def closed_loop(n):
+        done_view = g.done_view_device()
+
+        def closed_loop(n, one_call=True):
             for _ in range(n):
                 # the observation goes to the network as the list of its non-zeros (bit-identical results to the dense
                 # sf_observe_device + sf_policy_forward pair, tests/test_gpu_sparse_obs.py)
                 g.observe_sparse_device(d_keys.data_ptr(), d_vals.data_ptr(), d_counts.data_ptr(), d_pov.data_ptr(), SP_CAP)
                 g.observe_overflow_device(d_counts.data_ptr(), SP_CAP, d_fallback.data_ptr(), d_pov.data_ptr())
+                if one_call:
+                    # Agent::predict + update as the one call they are in the reference: the fresh memory of the agents
+                    # whose game restarted (read from the environment's own flags), the forward and the draw in the
+                    # forward's two launches — same results as the calls below, tests/test_gpu_sparse_obs.py
+                    pb.predict_sparse(d_keys.data_ptr(), d_vals.data_ptr(), d_counts.data_ptr(), d_pov.data_ptr(), SP_CAP, agents,
+                                      d_probs.data_ptr(), d_value.data_ptr(), d_pcmd.data_ptr(), seed=rank,
+                                      d_dense_ptr=d_fallback.data_ptr(), reset_words=done_view)
+                    g.step_device(d_pcmd.data_ptr(), 1)
+                    continue
                 pb.forward_sparse(d_keys.data_ptr(), d_vals.data_ptr(), d_counts.data_ptr(), d_pov.data_ptr(), SP_CAP, agents,
                                   d_probs.data_ptr(), d_value.data_ptr(), d_dense_ptr=d_fallback.data_ptr())
                 pb.act(d_probs.data_ptr(), agents, d_pcmd.data_ptr(), seed=rank)
@@ -524,6 +535,12 @@ def main():
                 g.done_device(d_new.data_ptr())      # agents whose game restarted get a fresh memory,
                 pb.reset_memory(d_new.data_ptr())    # like the reference's new Agent per game
 
+        closed_loop(2, False)
+        torch.cuda.synchronize()
+        pe3 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        pe3[0].record()
+        closed_loop(pol_n, False)
+        pe3[1].record()
         closed_loop(2)
         torch.cuda.synchronize()
         # the loop's rate first, with nothing but the two events around it; then once more with the library's per-launch
@@ -579,6 +596,7 @@ def main():
         pb4.close()
         pbl.close()
         pol = {"sparse_overflows": sp_over, "dense_fallback_agents_last_step": sp_fallback, "loop_ms": pe[0].elapsed_time(pe[1]) / pol_n,
+               "loop_ms_separate_calls": pe3[0].elapsed_time(pe3[1]) / pol_n,
                "by_kernel": [(m / pol_n, f / pol_n, n // pol_n) for (m, f, n) in by_k], "conv0_fma": conv0_fma, "nonzeros": nonzeros,
                "forward_ms_default_init": ev4[0].elapsed_time(ev4[1]) / 5, "forward_ms_gain4": ev4[1].elapsed_time(ev4[2]) / 5,
                "forward_ms_layered": ev4[2].elapsed_time(ev4[3]) / 5,
@@ -688,10 +706,15 @@ def main():
                 "what": "per rank: observe (as the list of non-zero floats) -> bot-0.5 network (f32 results, random-init weights; "
                         "the convolution stack — four bias-free convolutions with nothing between them — as one composed matrix on "
                         "those non-zeros, everything behind it in one kernel on the f32 MFMA) -> sample -> K=1 step -> memory reset "
-                        "of restarted games, all on device, %d steps; agents evaluated on a blank window: %d (lists that do not fit "
+                        "of restarted games, all on device, %d steps; sf_policy_predict_sparse: reset + forward + sample in the "
+                        "forward's two launches, five launches per step (separate_calls: the same loop through "
+                        "sf_policy_forward_sparse_or_dense / sf_policy_act / sf_done_device / sf_policy_reset_memory, eight); "
+                        "agents evaluated on a blank window: %d (lists that do not fit "
                         "are redone from a dense fallback on the device; %d agents took it in the last step)"
                         % (pol["steps"], pol["sparse_overflows"], pol["dense_fallback_agents_last_step"]),
                 "agent_steps_per_s": world * pol["agents"] / (pol["loop_ms"] / 1e3), "ms_per_step": pol["loop_ms"],
+                "separate_calls": {"agent_steps_per_s": world * pol["agents"] / (pol["loop_ms_separate_calls"] / 1e3),
+                                   "ms_per_step": pol["loop_ms_separate_calls"]},
                 "forward_ms": {"default_init": pol["forward_ms_default_init"], "weights_x4": pol["forward_ms_gain4"],
                                "layered": pol["forward_ms_layered"],
                                "what": "the forward alone (2 kernels) on the last step's lists: libtorch's default initialisation, "

@@ -268,6 +268,10 @@ int sf_done(sf_env *env, uint8_t *out_host);
  * layout the policy library's reset_memory entry (strikeforce_policy.h) takes: with auto_reset it marks the agents whose game just restarted, i.e. where the
  * reference would have built a new Agent in prepare() (gameplay.hpp:481). */
 int sf_done_device(sf_env *env, uint8_t *d_out);
+/* The same flags where the environment keeps them: arena a's is the int32 at (*d_words)[a * *stride_words], and each of
+ * its *agents_per_arena agents takes it (device memory owned by env, valid until sf_destroy, rewritten by every step) —
+ * for a consumer on the same stream that can read them in place (sf_policy_predict_sparse) instead of a copy. */
+int sf_done_view_device(sf_env *env, const int32_t **d_words, int32_t *stride_words, int32_t *agents_per_arena);
 
 /* ---- parity / tooling ---------------------------------------------------------------------- */
 int sf_state_digest(sf_env *env, uint64_t *out_host); /* one 64-bit digest per arena */

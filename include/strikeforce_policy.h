@@ -109,6 +109,38 @@ int sf_policy_sparse_overflows(sf_policy *p, int32_t *count);
 int sf_policy_act(sf_policy *p, const float *d_probs, int32_t agents, const char *action_string, uint64_t seed,
                   int32_t greedy, uint8_t *d_cmd, int32_t *d_action);
 
+/* Agent::predict() + Agent::update() as the ONE call they are in the reference (Agent.hpp:200-222), for the closed loop
+ * on the device: sf_policy_reset_memory + sf_policy_forward_sparse(_or_dense) + sf_policy_act in the forward's two
+ * launches, with the same results bit for bit as the three calls in that order (tests/test_gpu_policy.py).
+ *   d_keys .. cap   the observation lists (sf_observe_sparse_device), as sf_policy_forward_sparse takes them
+ *   d_dense         optional: dense rows for the lists that did not fit (sf_observe_overflow_device); without it such
+ *                   agents are evaluated on a blank window and counted (sf_policy_sparse_overflows)
+ *   d_reset_mask    optional, one byte per agent (sf_done_device's layout): non-zero = this agent's game restarted, it
+ *                   starts from a new Agent's memory (zero state, "no action" as its last action) — gameplay.hpp:481
+ *   d_reset_words   optional, the same flags where the environment keeps them (sf_done_view_device): agent a reads
+ *                   word (a / reset_group) * reset_stride — saves the sf_done_device launch
+ *   action_string, seed, greedy, d_cmd, d_action (may be NULL)   as in sf_policy_act
+ *   d_probs, d_value   as in sf_policy_forward_sparse
+ * The masks are read by the launch, in stream order: what sf_step_device left there is what counts. */
+typedef struct sf_policy_predict_io {
+  const uint32_t *d_keys;
+  const float *d_vals;
+  const uint32_t *d_counts;
+  const float *d_pov;
+  int32_t cap;
+  const float *d_dense;
+  const uint8_t *d_reset_mask;
+  const int32_t *d_reset_words;
+  int32_t reset_stride, reset_group;
+  const char *action_string;
+  uint64_t seed;
+  int32_t greedy;
+  float *d_probs, *d_value;
+  uint8_t *d_cmd;
+  int32_t *d_action;
+} sf_policy_predict_io;
+int sf_policy_predict_sparse(sf_policy *p, const sf_policy_predict_io *io, int32_t agents);
+
 /* Read/write one agent's recurrent state for tests: h [2][160] and the action one-hot [9] (host buffers). */
 int sf_policy_get_memory(sf_policy *p, int32_t agent, float *h, float *action_input);
 int sf_policy_set_memory(sf_policy *p, int32_t agent, const float *h, const float *action_input);

@@ -111,19 +111,6 @@ __global__ void k_agent_alive(Params p, uint8_t *out) {
   gptr(out)[i] = (uint8_t)((fl & (HF_ALIVE | HF_CTRL)) == (HF_ALIVE | HF_CTRL));
 }
 
-// sf_observe_overflow_device, second step: the 160 centre values of the agents whose list did not fit, from the dense
-// observation k_observe (mode 4) has just written for them (a crowded window's records do not cover every cell)
-__global__ void k_pov_from_dense(const uint32_t *counts, int cap, const float *dense, float *pov, int agents) {
-  const int i = (int)blockIdx.x;
-  const uint32_t c = gptr(counts)[i];
-  if (i >= agents || !(c == 0xffffffffu || c > (uint32_t)cap)) return;
-  const int t = (int)threadIdx.x;  // 160 threads: cell = t >> 5 of (-1,0) (0,-1) (0,0) (0,1) (1,0), channel = t & 31
-  const int cell = t >> 5, ch = t & 31;
-  const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0, dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
-  const int w = (SF_OBS_WINDOW / 2 + dy) * SF_OBS_WINDOW + (SF_OBS_WINDOW / 2 + dx);
-  gptr(pov)[(size_t)i * (5 * SF_OBS_CHANNELS) + t] = gptr(dense)[(size_t)i * SF_OBS_FLOATS + (size_t)ch * (SF_OBS_WINDOW * SF_OBS_WINDOW) + w];
-}
-
 // check_end()'s verdict per (arena, agent) on the device (sf_done_device)
 __global__ void k_done(Params p, uint8_t *out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -220,6 +207,7 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   const uint32_t hf = gptr(p.hum)[((size_t)HW_FLAGS * p.A + a) * p.H + g];
   const uint32_t center = gptr(p.hum)[((size_t)HW_POS * p.A + a) * p.H + g];
   SF_GLOBAL uint32_t *old = nzprev ? gptr(nzprev) + (size_t)blockIdx.x * OBS_W2 : nullptr;
+  const bool redo = mode == 4;
   if (mode == 4) {  // sf_observe_overflow_device: the plain dense write, but only for the agents whose list did not fit
     const uint32_t c = gptr(sp.counts)[blockIdx.x];
     if (!(c == 0xffffffffu || c > (uint32_t)sp.cap)) return;  // (uniform over the workgroup)
@@ -476,6 +464,16 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
         if (!obs_map_fast(tab, x, y)) y = obs_map(x);
         if (y != 0.f) o[k * OBS_W2 + w] = y;
       });
+    }
+  }
+  if (redo) {  // and the 160 centre values of such an agent, from the dense row just written (a crowded window's records
+               // do not cover every cell): cell = t >> 5 of (-1,0) (0,-1) (0,0) (0,1) (1,0), channel = t & 31
+    __syncthreads();  // (the workgroup's stores to the row are complete; this CU has not read the row before)
+    if (tid < 5 * SF_OBS_CHANNELS) {
+      const int cell = tid >> 5, ch = tid & 31;
+      const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0, dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
+      const int w = (SF_OBS_WINDOW / 2 + dy) * SF_OBS_WINDOW + (SF_OBS_WINDOW / 2 + dx);
+      gptr(sp.pov)[(size_t)blockIdx.x * (5 * SF_OBS_CHANNELS) + tid] = o[ch * OBS_W2 + w];
     }
   }
 }
@@ -977,9 +975,7 @@ struct HipRT {
     hipLaunchKernelGGL(k_observe, dim3((unsigned)n), dim3(OBS_THREADS),
                        obs_lds_bytes(p),
                        stream, p, dense, (uint32_t *)nullptr, 4,
-                       ObsSparse{nullptr, nullptr, const_cast<uint32_t *>(counts), nullptr, cap});
-    SF_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_pov_from_dense, dim3((unsigned)n), dim3(5 * SF_OBS_CHANNELS), 0, stream, counts, cap, dense, pov, n);
+                       ObsSparse{nullptr, nullptr, const_cast<uint32_t *>(counts), pov, cap});
     SF_HIP(hipGetLastError());
     return SF_OK;
   }
@@ -1140,6 +1136,10 @@ int sf_results_device(sf_env *env, int32_t *d_out) {
 int sf_done_device(sf_env *env, uint8_t *d_out) {
   SF_ENV(env);
   return env->e.done_device(d_out);
+}
+int sf_done_view_device(sf_env *env, const int32_t **d_words, int32_t *stride_words, int32_t *agents_per_arena) {
+  SF_ENV(env);
+  return env->e.done_view_device(d_words, stride_words, agents_per_arena);
 }
 int sf_done(sf_env *env, uint8_t *out_host) {
   SF_ENV(env);

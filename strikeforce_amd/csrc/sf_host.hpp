@@ -534,6 +534,12 @@ struct Env {
     return rt.launch_done(p, d_out);
   }
 
+  int done_view_device(const int32_t **d_words, int32_t *stride, int32_t *group) {
+    if (!d_words || !stride || !group) return fail(SF_ERR_ARG, "null argument");
+    *d_words = p.scal + (p.auto_reset ? SC_ENDED : SC_DONE), *stride = SC_WORDS, *group = p.n_agents;
+    return SF_OK;
+  }
+
   // ---- parity tooling ----------------------------------------------------------------------------
   int snapshot() {
     const size_t A = (size_t)p.A;

@@ -1259,6 +1259,47 @@ constexpr int TL_FLOATS = TL_H1 + TL_R * TL_LD;
 constexpr int TL_LDS = TL_FLOATS * 4;                // 158 720 bytes
 static_assert(TL_COMB + TL_R * TL_LDC <= TL_B0 && TL_X1 + TL_R * TL_LD <= TL_B0, "region A holds its tenants");
 
+__device__ inline uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct ActStr {
+  char c[ACT];
+};
+
+// The tail of Agent::predict() (Agent.hpp:200-216) for agent a: v[0] = 0.5, the rest scaled to 0.5 in all, one draw from
+// discrete_distribution(v) — or the arg-max.  One body for k_act and for k_tail's last lines (sf_policy_predict_sparse).
+__device__ inline int act_pick(float (&v)[ACT], uint64_t seed, uint64_t draw, int greedy, int a) {
+  const float sc = 0.5f / (1.f - v[0] + 1e-5f);
+#pragma unroll
+  for (int k = 1; k < ACT; ++k) v[k] *= sc;
+  v[0] = 0.5f;
+  int pick = 0;
+  if (greedy) {
+#pragma unroll
+    for (int k = 1; k < ACT; ++k)
+      if (v[k] > v[pick]) pick = k;
+  } else {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < ACT; ++k) tot += v[k];
+    const uint64_t r = mix64(mix64(seed ^ mix64((uint64_t)a)) + draw);
+    const float u = (float)(r >> 40) * (1.0f / 16777216.0f) * tot;  // [0, tot)
+    float c = 0.f;
+    bool found = false;
+    pick = ACT - 1;
+#pragma unroll
+    for (int k = 0; k < ACT - 1; ++k) {
+      c += v[k];
+      if (!found && u < c) pick = k, found = true;
+    }
+  }
+  return pick;
+}
+
 struct TailArgs {
   const float *act2, *obs, *pov, *conv3_w;  // pov: the 160 centre values as a dense row per agent, or null (gather them from obs)
   const float *feat;                        // the folded convolution stack's output (k_feat_*): conv3 is then not run here
@@ -1266,9 +1307,21 @@ struct TailArgs {
   const float *comb_w, *comb_b;
   const float *res_w[2][3], *res_b[2][3], *head_w[2], *head_b[2];
   float *h[2];
-  const float *action_input;
+  float *action_input;  // (read at the start; written by the folded sf_policy_act)
   float *probs, *value;
   int agents;
+  // sf_policy_predict_sparse: the calls around the forward folded into it
+  //   before: sf_policy_reset_memory — an agent whose mask byte, or whose arena's word, is non-zero starts from h = 0 and
+  //           the "no action" one-hot instead of what is stored
+  //   after:  sf_policy_act — the draw, the one-hot for the next call, the command char (act != 0)
+  const uint8_t *reset_mask;   // [agents] or null
+  const int32_t *reset_words;  // word (a / reset_group) * reset_stride, or null (sf_done_view_device)
+  int reset_stride, reset_group;
+  int act, greedy;
+  ActStr as;
+  uint64_t seed, draw;
+  uint8_t *cmd;
+  int32_t *action;
 };
 
 // out[r][n0 + c] = bias[n0 + c] + sum_k in[r][k] * W[n0 + c][k] for the 16 agents r and 16 columns c of one tile
@@ -1316,11 +1369,16 @@ constexpr int TS_U = 5;
 struct TsBuf {  // (passed and returned by value: every element stays a register)
   f32x4 v[TS_U];
 };
-__device__ inline const float *ts_wp(const float *W, int K, int n0, int l) { return W + (size_t)(n0 + (l & 15)) * K + 4 * (l >> 4); }
+// The streamed weights are stored in the order the loads take them (upload_tiles(), sf_policy_create): tile (16 output
+// columns) by tile, k-step (16 inputs) by k-step, lane by lane — one k-step of a tile is 1 KB that a wave's
+// global_load_dwordx4 reads as eight whole 128-byte lines.  (From the row-major matrix the same load touched sixteen
+// lines, half of each, and the vector L1's tag pipe — not the L2, not the matrix pipe — set the pace of the tile phases:
+// in-kernel stamps, round 4.)
+__device__ inline const float *ts_wp(const float *W, int K, int n0, int l) { return W + (size_t)(n0 >> 4) * ((size_t)K * 16) + 4 * l; }
 template <int N>
 __device__ inline TsBuf ts_issue(TsBuf b, const float *wp, int s0) {
 #pragma unroll
-  for (int u = 0; u < N; ++u) b.v[u] = ldg4(wp + 16 * (s0 + u));
+  for (int u = 0; u < N; ++u) b.v[u] = ldg4(wp + 256 * (s0 + u));
   return b;
 }
 template <int N>
@@ -1417,6 +1475,11 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
   const int a_raw = blockIdx.x * TL_R + w;
   const bool valid = a_raw < t.agents;
   const int a = valid ? a_raw : t.agents - 1;  // a ragged last workgroup computes its missing rows on the last agent, stores nothing
+  // a restarted game's agent is a new Agent (gameplay.hpp:481): zero memory, "no action" as its last action
+  bool fresh = false;  // (uniform over the wave)
+  if (t.reset_mask) fresh = t.reset_mask[a] != 0;
+  if (t.reset_words) fresh = fresh || t.reset_words[(size_t)(a / t.reset_group) * (size_t)t.reset_stride] != 0;
+  fresh = __builtin_amdgcn_readfirstlane((int)fresh) != 0;
   // ---- conv3's input (act2 row = 9 pixels x 160 channels, the K order of the permuted weight) and h0
   {
     if (!t.feat) {
@@ -1424,7 +1487,7 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
       f32x4 *dst = reinterpret_cast<f32x4 *>(tl + TL_A + w * TL_LDX);
       for (int i = l; i < 9 * HID / 4; i += 64) dst[i] = src[i];
     }
-    row_store(tl + TL_B1 + w * TL_LD, l, row_load(t.h[0] + (size_t)a * HID, l));
+    row_store(tl + TL_B1 + w * TL_LD, l, fresh ? Row3{} : row_load(t.h[0] + (size_t)a * HID, l));
   }
   // fetched now, used after gru0: the agent's pov (5 cells x 32 channels around the centre of the observation, then the
   // action one-hot) and its h1 — 160 scattered HBM lines, issued together with conv3's input
@@ -1444,11 +1507,11 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
           v = op[(size_t)ch * OBS_W * OBS_W + (OBS_W / 2 + dy) * OBS_W + (OBS_W / 2 + dx)];
         }
       } else if (e < POV) {
-        v = t.action_input[(size_t)a * ACT + (e - 5 * OBS_C)];
+        v = fresh ? (e == 5 * OBS_C ? 1.f : 0.f) : t.action_input[(size_t)a * ACT + (e - 5 * OBS_C)];
       }
       tl[TL_PV + w * TL_LDP + e] = v;
     }
-    row_store(tl + TL_H1 + w * TL_LD, l, row_load(t.h[1] + (size_t)a * HID, l));
+    row_store(tl + TL_H1 + w * TL_LD, l, fresh ? Row3{} : row_load(t.h[1] + (size_t)a * HID, l));
   }
   // the weight stream (see ts_tile160): where each of this wave's tiles lives
   TsBuf b0 = {}, b1 = {};
@@ -1460,19 +1523,23 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     const int hd = tt >= HID / 16, n0 = 16 * (tt - hd * (HID / 16));
     return ts_wp(t.res_w[hd][i], HID, n0, l);
   };
-  if (t.feat) b0 = ts_issue<5>(b0, gru_wp(0, w), 0);  // (folded form: gru0's first tile is this wave's first)
-  TL_STAMP(0);
-  tail_barrier();
-  TL_STAMP(1);
-  if (t.feat) {
-    row_store(tl + TL_Y0 + w * TL_LD, l, row_load(t.feat + (size_t)a * HID, l));
+  if (t.feat) {  // folded form: gru0's first tile is this wave's first, and feat_n is a row of its own agent     :108
+    const Row3 fr = row_load(t.feat + (size_t)a * HID, l);
+    b0 = ts_issue<5>(b0, gru_wp(0, w), 0);
+    row_store(tl + TL_B0 + w * TL_LD, l, row_norm(fr));
+    TL_STAMP(0);
+    TL_STAMP(1);
+    TL_STAMP(2);
   } else {
+    TL_STAMP(0);
+    tail_barrier();
+    TL_STAMP(1);
     if (w < HID / 16) tail_tile<9 * HID>(tl + TL_A, TL_LDX, t.conv3_w, nullptr, tl + TL_Y0, TL_LD, 16 * w, l);  // Modules.hpp:66-71
     b0 = ts_issue<5>(b0, gru_wp(0, w), 0);
+    tail_barrier();
+    row_store(tl + TL_B0 + w * TL_LD, l, row_norm(row_load(tl + TL_Y0 + w * TL_LD, l)));  // feat_n :108
+    TL_STAMP(2);
   }
-  tail_barrier();
-  row_store(tl + TL_B0 + w * TL_LD, l, row_norm(row_load(tl + TL_Y0 + w * TL_LD, l)));  // feat_n :108
-  TL_STAMP(2);
   tail_barrier();
   TL_STAMP(3);
   // ---- gru0: gi = W_ih feat_n + b_ih, gh = W_hh h0 + b_hh (30 + 30 tiles)                          :110-113
@@ -1598,10 +1665,29 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
       s += e;
       mine = (l == k) ? e : mine;
     }
-    if (l < ACT) t.probs[(size_t)a * ACT + l] = mine / s + 1e-8f;
+    const float pl = mine / s + 1e-8f;
+    if (l < ACT) t.probs[(size_t)a * ACT + l] = pl;
     if (l == 0) t.value[a] = sigmoidf_(tl[TL_LIN1 + w * TL_LD]);
+    if (t.act) {  // sf_policy_act on the probabilities just stored (lanes 0..8 hold them)
+      float v[ACT];
+#pragma unroll
+      for (int k = 0; k < ACT; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pl), k));
+      const int pick = act_pick(v, t.seed, t.draw, t.greedy, a);
+      if (l < ACT) t.action_input[(size_t)a * ACT + l] = (l == pick) ? 1.f : 0.f;
+      if (l == 0) {
+        char c = t.as.c[0];
+#pragma unroll
+        for (int k = 1; k < ACT; ++k) c = (pick == k) ? t.as.c[k] : c;  // (a chain of selects: no indexed copy of the argument)
+        t.cmd[a] = (uint8_t)c;
+        if (t.action) t.action[a] = pick;
+      }
+    }
   }
   TL_STAMP(22);
+#ifdef SF_DIAG_TAIL
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096u)  // HW_ID: which SIMD / CU this wave ran on
+    sf_diag_tail[(blockIdx.x * 16u + (threadIdx.x >> 6)) * 24u + 23u] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
 }
 
 __global__ void k_reset_memory(float *h0, float *h1, float *action_input, const uint8_t *mask, int agents) {
@@ -1612,17 +1698,6 @@ __global__ void k_reset_memory(float *h0, float *h1, float *action_input, const 
   if (e < ACT) action_input[(size_t)a * ACT + e] = (e == 0) ? 1.f : 0.f;
 }
 
-__device__ inline uint64_t mix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
-struct ActStr {
-  char c[ACT];
-};
-
 // Agent::predict tail + Agent::update (Agent.hpp:200-222)
 __global__ void k_act(const float *probs, float *action_input, ActStr as, uint64_t seed, uint64_t draw, int greedy,
                       uint8_t *cmd, int32_t *action, int agents) {
@@ -1631,30 +1706,7 @@ __global__ void k_act(const float *probs, float *action_input, ActStr as, uint64
   float v[ACT];
 #pragma unroll
   for (int k = 0; k < ACT; ++k) v[k] = probs[(size_t)a * ACT + k];
-  const float sc = 0.5f / (1.f - v[0] + 1e-5f);
-#pragma unroll
-  for (int k = 1; k < ACT; ++k) v[k] *= sc;
-  v[0] = 0.5f;
-  int pick = 0;
-  if (greedy) {
-#pragma unroll
-    for (int k = 1; k < ACT; ++k)
-      if (v[k] > v[pick]) pick = k;
-  } else {
-    float tot = 0.f;
-#pragma unroll
-    for (int k = 0; k < ACT; ++k) tot += v[k];
-    const uint64_t r = mix64(mix64(seed ^ mix64((uint64_t)a)) + draw);
-    const float u = (float)(r >> 40) * (1.0f / 16777216.0f) * tot;  // [0, tot)
-    float c = 0.f;
-    bool found = false;
-    pick = ACT - 1;
-#pragma unroll
-    for (int k = 0; k < ACT - 1; ++k) {
-      c += v[k];
-      if (!found && u < c) pick = k, found = true;
-    }
-  }
+  const int pick = act_pick(v, seed, draw, greedy, a);
 #pragma unroll
   for (int k = 0; k < ACT; ++k) action_input[(size_t)a * ACT + k] = (k == pick) ? 1.f : 0.f;
   cmd[a] = (uint8_t)as.c[pick];
@@ -1719,6 +1771,11 @@ struct Policy {
   float *comb_w = nullptr, *comb_b = nullptr;
   float *res_w[2][3] = {}, *res_b[2][3] = {}, *head_w[2] = {}, *head_b[2] = {};  // [0] policy, [1] value
   float *head_w16[2] = {}, *head_b16[2] = {};  // the same padded with zero rows to one 16-column MFMA tile (k_tail)
+  // k_tail's copies of its matrices in the order its weight stream reads them (stage_tiles), ONE block in the order of use
+  // (2.09 MB)
+  float *tail_w = nullptr;
+  std::vector<float> tail_stage;  // (host side, until sf_policy_create has uploaded it)
+  size_t gru_w_ih_t[2] = {}, gru_w_hh_t[2] = {}, comb_w_t = 0, res_w_t[2][3] = {}, head_w16_t[2] = {};  // offsets in floats
   // per-agent state and scratch
   float *h[2] = {}, *action_input = nullptr;
   float *act[3] = {};  // NHWC conv outputs 15x15, 7x7, 3x3
@@ -1741,6 +1798,19 @@ struct Policy {
     if (hipMalloc(&d, floats * sizeof(float)) != hipSuccess) return fail(SF_ERR_MEMORY, "hipMalloc failed (policy)");
     owned.push_back(d);
     *p = (float *)d;
+    return SF_OK;
+  }
+  // k_tail's weight stream order (ts_wp / ts_issue): Wt[tile][k-step][lane][j] = W[16 tile + (lane & 15)][16 k-step + 4 (lane >> 4) + j]
+  int stage_tiles(size_t *off, const float *src, int N, int K) {
+    if (!src) return fail(SF_ERR_ARG, "sf_policy_weights has a null pointer");
+    *off = tail_stage.size();
+    tail_stage.resize(*off + (size_t)N * K);
+    float *t = tail_stage.data() + *off;
+    for (int tile = 0; tile < N / 16; ++tile)
+      for (int st = 0; st < K / 16; ++st)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 4; ++j)
+            t[(((size_t)tile * (K / 16) + st) * 64 + l) * 4 + j] = src[(size_t)(16 * tile + (l & 15)) * K + 16 * st + 4 * (l >> 4) + j];
     return SF_OK;
   }
   int upload(float **p, const float *src, size_t floats) {
@@ -1955,10 +2025,18 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
     std::vector<float> pad((size_t)HID * COMB_PAD, 0.f);
     for (int nn = 0; nn < HID; ++nn) std::memcpy(&pad[(size_t)nn * COMB_PAD], w->comb_w + (size_t)nn * COMB, COMB * sizeof(float));
     SFP_TRY(p->upload(&p->comb_w, pad.data(), pad.size()));
+    // k_tail's block, in the order the kernel goes through it
+    SFP_TRY(p->stage_tiles(&p->gru_w_ih_t[0], w->gru_w_ih[0], G3, HID));
+    SFP_TRY(p->stage_tiles(&p->gru_w_hh_t[0], w->gru_w_hh[0], G3, HID));
+    SFP_TRY(p->stage_tiles(&p->comb_w_t, pad.data(), HID, COMB_PAD));
+    SFP_TRY(p->stage_tiles(&p->gru_w_ih_t[1], w->gru_w_ih[1], G3, HID));
+    SFP_TRY(p->stage_tiles(&p->gru_w_hh_t[1], w->gru_w_hh[1], G3, HID));
     SFP_TRY(p->upload(&p->comb_b, w->comb_b, HID));
   }
   for (int i = 0; i < 3; ++i) {
     SFP_TRY(p->upload(&p->res_w[0][i], w->policy_res_w[i], (size_t)HID * HID));
+    SFP_TRY(p->stage_tiles(&p->res_w_t[0][i], w->policy_res_w[i], HID, HID));
+    SFP_TRY(p->stage_tiles(&p->res_w_t[1][i], w->value_res_w[i], HID, HID));
     SFP_TRY(p->upload(&p->res_b[0][i], w->policy_res_b[i], HID));
     SFP_TRY(p->upload(&p->res_w[1][i], w->value_res_w[i], (size_t)HID * HID));
     SFP_TRY(p->upload(&p->res_b[1][i], w->value_res_b[i], HID));
@@ -1973,8 +2051,11 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
     std::memcpy(wpad.data(), g ? w->value_w : w->policy_w, (size_t)rows * HID * sizeof(float));
     std::memcpy(bpad.data(), g ? w->value_b : w->policy_b, (size_t)rows * sizeof(float));
     SFP_TRY(p->upload(&p->head_w16[g], wpad.data(), wpad.size()));
+    SFP_TRY(p->stage_tiles(&p->head_w16_t[g], wpad.data(), 16, HID));
     SFP_TRY(p->upload(&p->head_b16[g], bpad.data(), bpad.size()));
   }
+  SFP_TRY(p->upload(&p->tail_w, p->tail_stage.data(), p->tail_stage.size()));
+  std::vector<float>().swap(p->tail_stage);
   const size_t B = (size_t)max_agents;
   SFP_TRY(p->dalloc(&p->h[0], B * HID));
   SFP_TRY(p->dalloc(&p->h[1], B * HID));
@@ -2010,12 +2091,23 @@ static int create(const sf_policy_weights *w, int max_agents, int device, sf_pol
 
 // li + d_obs together: list form with a dense fallback for the agents whose list did not fit (d_obs need only be valid
 // for those: sf_observe_overflow_device)
+struct PredictExtra {  // what sf_policy_predict_sparse folds into k_tail (see TailArgs)
+  const uint8_t *reset_mask;
+  const int32_t *reset_words;
+  int reset_stride, reset_group;
+  ActStr as;
+  uint64_t seed;
+  int greedy;
+  uint8_t *cmd;
+  int32_t *action;
+};
 static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, float *d_value, const C0List *li = nullptr,
-                   const float *d_pov = nullptr) {
+                   const float *d_pov = nullptr, const PredictExtra *px = nullptr) {
   int rc = check_agents(p, agents);
   if (rc) return rc;
   if ((!d_obs && !li) || !d_probs || !d_value) return fail(SF_ERR_ARG, "null buffer");
   if (li && !p->fused_tail) return fail(SF_ERR_STATE, "sf_policy_forward_sparse needs the fused tail (SF_POLICY_FUSED_TAIL=0 is set)");
+  if (px && !p->fused_tail) return fail(SF_ERR_STATE, "sf_policy_predict_sparse needs the fused tail (SF_POLICY_FUSED_TAIL=0 is set)");
   SFP_HIP(hipSetDevice(p->device));
   const dim3 rg((unsigned)((agents + 3) / 4)), rb(256);
   hipStream_t st = p->stream;
@@ -2060,13 +2152,24 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
     t.act2 = p->act[2], t.obs = d_obs, t.pov = d_pov, t.conv3_w = p->conv_w[3];
     t.feat = p->folded ? p->feat : nullptr;
     for (int g = 0; g < 2; ++g) {
-      t.gru_w_ih[g] = p->gru_w_ih[g], t.gru_w_hh[g] = p->gru_w_hh[g], t.gru_b_ih[g] = p->gru_b_ih[g], t.gru_b_hh[g] = p->gru_b_hh[g];
-      t.h[g] = p->h[g], t.head_w[g] = p->head_w16[g], t.head_b[g] = p->head_b16[g];
-      for (int i = 0; i < 3; ++i) t.res_w[g][i] = p->res_w[g][i], t.res_b[g][i] = p->res_b[g][i];
+      // (the matrices in k_tail's stream order, stage_tiles)
+      t.gru_w_ih[g] = p->tail_w + p->gru_w_ih_t[g], t.gru_w_hh[g] = p->tail_w + p->gru_w_hh_t[g], t.gru_b_ih[g] = p->gru_b_ih[g], t.gru_b_hh[g] = p->gru_b_hh[g];
+      t.h[g] = p->h[g], t.head_w[g] = p->tail_w + p->head_w16_t[g], t.head_b[g] = p->head_b16[g];
+      for (int i = 0; i < 3; ++i) t.res_w[g][i] = p->tail_w + p->res_w_t[g][i], t.res_b[g][i] = p->res_b[g][i];
     }
-    t.comb_w = p->comb_w, t.comb_b = p->comb_b, t.action_input = p->action_input;
+    t.comb_w = p->tail_w + p->comb_w_t, t.comb_b = p->comb_b, t.action_input = p->action_input;
+
     t.probs = d_probs, t.value = d_value, t.agents = agents;
+    t.reset_group = 1;
+    if (px) {
+      t.reset_mask = px->reset_mask, t.reset_words = px->reset_words, t.reset_stride = px->reset_stride;
+      t.reset_group = px->reset_group > 0 ? px->reset_group : 1;
+      t.act = 1, t.greedy = px->greedy, t.as = px->as, t.seed = px->seed, t.draw = p->draws++, t.cmd = px->cmd, t.action = px->action;
+    }
     hipLaunchKernelGGL(k_tail, dim3((unsigned)((agents + TL_R - 1) / TL_R)), dim3(TL_T), TL_LDS, st, t);
+#ifdef SF_DIAG_TAIL  // (diagnostic build: the stamps of a second launch, whose weights the first one left in the L2s)
+    if (std::getenv("SF_DIAG_TAIL_TWICE")) hipLaunchKernelGGL(k_tail, dim3((unsigned)((agents + TL_R - 1) / TL_R)), dim3(TL_T), TL_LDS, st, t);
+#endif
     SFP_HIP(hipGetLastError());
     if (e1) SFP_HIP(hipEventRecord(e1, st));
     return SF_OK;
@@ -2179,6 +2282,23 @@ int sf_policy_forward_sparse_or_dense(sf_policy *pp, const uint32_t *d_keys, con
   if (cap > SF_POLICY_LIST_MAX) return sfp::fail(SF_ERR_ARG, "cap above SF_POLICY_LIST_MAX (2048)");
   const sfp::C0List li{d_keys, d_vals, d_counts, cap, nullptr};
   return sfp::forward(p, d_dense, agents, d_probs, d_value, &li, d_pov);
+}
+
+int sf_policy_predict_sparse(sf_policy *pp, const sf_policy_predict_io *io, int32_t agents) {
+  Policy *p = reinterpret_cast<Policy *>(pp);
+  if (!p || !io) return sfp::fail(SF_ERR_ARG, "null policy or io");
+  if (!io->d_keys || !io->d_vals || !io->d_counts || !io->d_pov || io->cap < 1) return sfp::fail(SF_ERR_ARG, "null buffer or cap < 1");
+  if (io->cap > SF_POLICY_LIST_MAX) return sfp::fail(SF_ERR_ARG, "cap above SF_POLICY_LIST_MAX (2048)");
+  if (!io->d_cmd || !io->action_string) return sfp::fail(SF_ERR_ARG, "null buffer");
+  if (std::strlen(io->action_string) != (size_t)sfp::ACT) return sfp::fail(SF_ERR_ARG, "action_string must have 9 chars");
+  if (io->d_reset_words && (io->reset_stride < 1 || io->reset_group < 1)) return sfp::fail(SF_ERR_ARG, "reset_stride and reset_group must be positive");
+  sfp::PredictExtra px{};
+  px.reset_mask = io->d_reset_mask, px.reset_words = io->d_reset_words, px.reset_stride = io->reset_stride, px.reset_group = io->reset_group;
+  std::memcpy(px.as.c, io->action_string, sfp::ACT);
+  px.seed = io->seed, px.greedy = io->greedy, px.cmd = io->d_cmd, px.action = io->d_action;
+  // (without d_dense: lists that do not fit are counted, as in sf_policy_forward_sparse)
+  const sfp::C0List li{io->d_keys, io->d_vals, io->d_counts, io->cap, io->d_dense ? nullptr : p->d_overflows};
+  return sfp::forward(p, io->d_dense, agents, io->d_probs, io->d_value, &li, io->d_pov, &px);
 }
 
 #ifdef SF_DIAG_TAIL

@@ -50,6 +50,8 @@ def load_library():
         L.sf_observe_overflow_device.restype = C.c_int
         L.sf_results_device.argtypes = [vp, vp]
         L.sf_done_device.argtypes = [vp, vp]
+        L.sf_done_view_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.sf_done_view_device.restype = C.c_int
         L.sf_set_stream.argtypes = [vp, vp]
         L.sf_synchronize.argtypes = [vp]
         L.sf_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -75,7 +77,7 @@ def load_library():
 
 # every symbol include/strikeforce.h declares
 EXPORTS = ["sf_create", "sf_destroy", "sf_config_defaults", "sf_reset", "sf_step", "sf_step_device", "sf_observe",
-           "sf_observe_device", "sf_observe_device_delta", "sf_observe_sparse_device", "sf_observe_overflow_device", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_state_digest", "sf_dump_arena",
+           "sf_observe_device", "sf_observe_device_delta", "sf_observe_sparse_device", "sf_observe_overflow_device", "sf_results", "sf_results_device", "sf_done", "sf_done_device", "sf_done_view_device", "sf_state_digest", "sf_dump_arena",
            "sf_set_stream", "sf_synchronize", "sf_kernel_time", "sf_last_error", "sf_abi_version",
            "sf_comm_unique_id", "sf_comm_init", "sf_results_allgather", "sf_comm_wait", "sf_comm_ranks",
            "sf_step_begin", "sf_step_end", "sf_step_end_device", "sf_agent_alive", "sf_agent_alive_device", "sf_phase_draws"]
@@ -226,6 +228,13 @@ class ArenaBatch:
     def done_device(self, d_out_ptr):
         """check_end()'s verdict on the device, one byte per (arena, agent): what PolicyBatch.reset_memory takes."""
         self._ck(self.L.sf_done_device(self.h, C.c_void_p(d_out_ptr)), "sf_done_device")
+
+    def done_view_device(self):
+        """The same flags where the library keeps them: (device pointer, int32 stride, agents per arena) — what
+        PolicyBatch.predict_sparse reads in place (reset_words=)."""
+        ptr, stride, group = C.c_void_p(), C.c_int32(), C.c_int32()
+        self._ck(self.L.sf_done_view_device(self.h, C.byref(ptr), C.byref(stride), C.byref(group)), "sf_done_view_device")
+        return ptr.value, stride.value, group.value
 
     def done(self):
         out = np.zeros(self.cfg.arenas, dtype=np.uint8)

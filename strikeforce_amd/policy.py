@@ -101,10 +101,19 @@ def load_checkpoint(path):
     return out
 
 
+class PredictIO(C.Structure):
+    """sf_policy_predict_io (include/strikeforce_policy.h)."""
+    _fields_ = [("d_keys", C.c_void_p), ("d_vals", C.c_void_p), ("d_counts", C.c_void_p), ("d_pov", C.c_void_p), ("cap", C.c_int32),
+                ("d_dense", C.c_void_p), ("d_reset_mask", C.c_void_p), ("d_reset_words", C.c_void_p),
+                ("reset_stride", C.c_int32), ("reset_group", C.c_int32), ("action_string", C.c_char_p), ("seed", C.c_uint64),
+                ("greedy", C.c_int32), ("d_probs", C.c_void_p), ("d_value", C.c_void_p), ("d_cmd", C.c_void_p), ("d_action", C.c_void_p)]
+
+
 def _bind(L):
     if getattr(L, "_sf_policy_bound", False):
         return
     vp = C.c_void_p
+    L.sf_policy_predict_sparse.argtypes = [vp, C.POINTER(PredictIO), C.c_int32]
     L.sf_policy_create.argtypes = [C.POINTER(Weights), C.c_int32, C.c_int32, C.POINTER(vp)]
     L.sf_policy_destroy.argtypes = [vp]
     L.sf_policy_destroy.restype = None
@@ -135,7 +144,7 @@ def _bind(L):
 # every symbol include/strikeforce_policy.h declares
 EXPORTS = ["sf_policy_create", "sf_policy_destroy", "sf_policy_reset_memory", "sf_policy_reset_memory_n", "sf_policy_forward", "sf_policy_forward_sparse",
            "sf_policy_forward_sparse_or_dense",
-           "sf_policy_sparse_overflows", "sf_policy_act",
+           "sf_policy_sparse_overflows", "sf_policy_act", "sf_policy_predict_sparse",
            "sf_policy_get_memory", "sf_policy_set_memory", "sf_policy_set_stream", "sf_policy_synchronize",
            "sf_policy_kernel_time", "sf_policy_kernel_time_ex", "sf_policy_kernel_time_by_kernel", "sf_policy_gemm", "sf_policy_gemm_split", "sf_policy_features", "sf_policy_abi_version"]
 
@@ -233,6 +242,20 @@ class PolicyBatch:
         n = C.c_int32()
         self._ck(self.L.sf_policy_sparse_overflows(self.h, C.byref(n)), "sf_policy_sparse_overflows")
         return n.value
+
+    def predict_sparse(self, d_keys_ptr, d_vals_ptr, d_counts_ptr, d_pov_ptr, cap, agents, d_probs_ptr, d_value_ptr, d_cmd_ptr,
+                       seed=0, greedy=False, d_action_ptr=None, action_string=ACTION_STRING, d_dense_ptr=None, d_reset_mask_ptr=None,
+                       reset_words=None):
+        """reset_memory(mask) + forward_sparse + act as the forward's two launches (Agent::predict + update are one call in
+        the reference too): same results bit for bit.  reset_words: ArenaBatch.done_view_device()'s triple, read in place."""
+        io = PredictIO()
+        io.d_keys, io.d_vals, io.d_counts, io.d_pov, io.cap = d_keys_ptr, d_vals_ptr, d_counts_ptr, d_pov_ptr, int(cap)
+        io.d_dense, io.d_reset_mask = d_dense_ptr, d_reset_mask_ptr
+        if reset_words is not None:
+            io.d_reset_words, io.reset_stride, io.reset_group = reset_words
+        io.action_string, io.seed, io.greedy = action_string.encode(), seed, 1 if greedy else 0
+        io.d_probs, io.d_value, io.d_cmd, io.d_action = d_probs_ptr, d_value_ptr, d_cmd_ptr, d_action_ptr
+        self._ck(self.L.sf_policy_predict_sparse(self.h, C.byref(io), int(agents)), "sf_policy_predict_sparse")
 
     def act(self, d_probs_ptr, agents, d_cmd_ptr, seed=0, greedy=False, d_action_ptr=None,
             action_string=ACTION_STRING):

@@ -219,3 +219,88 @@ def test_agents_whose_list_does_not_fit_are_evaluated_from_the_dense_fallback(wh
     assert sparse.sparse_overflows() == 0
     if which != "MAXCAP":
         assert flagged > 0
+
+
+@pytest.mark.parametrize("resets", ["mask", "words", "both"])
+def test_predict_is_reset_forward_act_in_one_call(resets, cnn):
+    """sf_policy_predict_sparse = sf_policy_reset_memory + sf_policy_forward_sparse_or_dense + sf_policy_act folded into the
+    forward's two launches (Agent::predict + update are one call in the reference, Agent.hpp:200-222): probabilities,
+    value, command, action, and every agent's memory afterwards equal the three calls' bit for bit over recurrent steps —
+    with the restart flags as a byte per agent, as words read in place (sf_done_view_device's layout: one word per arena,
+    a stride apart), or both."""
+    w = config.baseline_workload("C5", arenas=5)  # 8 agents per arena
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    B, G = w.cfg.arenas * w.cfg.n_agents, w.cfg.n_agents
+    params = policy.init_parameters(seed=6)
+    three, one = policy.PolicyBatch(params, B), policy.PolicyBatch(params, B)
+    keys, vals, counts, pov = _bufs(B)
+    d_fb = torch.full((B, 32, 31, 31), float("nan"), dtype=torch.float32, device="cuda")
+    out = [(torch.zeros((B, 9), device="cuda"), torch.zeros(B, device="cuda"), torch.zeros(B, dtype=torch.uint8, device="cuda"),
+            torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(2)]
+    rng = np.random.default_rng(11)
+    STRIDE = 3
+    for step in range(6):
+        _advance(w, g, 25)
+        mask = (rng.random(B) < 0.3).astype(np.uint8) if resets in ("mask", "both") else np.zeros(B, dtype=np.uint8)
+        words = np.zeros(w.cfg.arenas * STRIDE, dtype=np.int32)
+        if resets in ("words", "both"):
+            words[::STRIDE] = (rng.random(w.cfg.arenas) < 0.4) * rng.integers(1, 300, w.cfg.arenas)
+            words[1::STRIDE] = 7  # (the words in between are not flags)
+        both = mask | (np.repeat(words[::STRIDE], G) != 0).astype(np.uint8)
+        d_mask, d_words, d_both = torch.from_numpy(mask).cuda(), torch.from_numpy(words).cuda(), torch.from_numpy(both).cuda()
+        g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP)
+        g.observe_overflow_device(counts.data_ptr(), CAP, d_fb.data_ptr(), pov.data_ptr())
+        g.synchronize()
+        if step:  # (the first step: both start from sf_policy_create's fresh memory)
+            three.reset_memory(d_both.data_ptr())
+        three.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP, B, out[0][0].data_ptr(),
+                             out[0][1].data_ptr(), d_dense_ptr=d_fb.data_ptr())
+        three.act(out[0][0].data_ptr(), B, out[0][2].data_ptr(), seed=5, greedy=(step == 4), d_action_ptr=out[0][3].data_ptr())
+        one.predict_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP, B, out[1][0].data_ptr(),
+                           out[1][1].data_ptr(), out[1][2].data_ptr(), seed=5, greedy=(step == 4), d_action_ptr=out[1][3].data_ptr(),
+                           d_dense_ptr=d_fb.data_ptr(), d_reset_mask_ptr=d_mask.data_ptr() if step and resets != "words" else None,
+                           reset_words=(d_words.data_ptr(), STRIDE, G) if step and resets != "mask" else None)
+        three.synchronize(), one.synchronize()
+        for x, y in zip(out[0], out[1]):
+            assert torch.equal(x, y)
+        for b in range(B):
+            h3, a3 = three.get_memory(b)
+            h1, a1 = one.get_memory(b)
+            assert np.array_equal(h3, h1) and np.array_equal(a3, a1)
+        if step != 4:  # (the arg-max of v is always action 0: v[0] = 0.5 is half of the mass)
+            assert len(set(out[0][3].cpu().numpy().tolist())) > 1
+
+
+def test_the_done_view_is_what_sf_done_device_copies():
+    """sf_done_view_device: sf_policy_predict_sparse reading the environment's restart flags in place gives what
+    sf_done_device + sf_policy_reset_memory give, on games that really end (configs[0], 64 arenas, 4 800 steps)."""
+    w = config.baseline_workload("C1", arenas=64)
+    g = env.ArenaBatch(w)
+    g.reset(*w.seeds())
+    B = w.cfg.arenas * w.cfg.n_agents
+    view = g.done_view_device()
+    assert view[2] == w.cfg.n_agents and view[1] >= 1
+    params = policy.init_parameters(seed=8)
+    three, one = policy.PolicyBatch(params, B), policy.PolicyBatch(params, B)
+    keys, vals, counts, pov = _bufs(B)
+    out = [(torch.zeros((B, 9), device="cuda"), torch.zeros(B, device="cuda"), torch.zeros(B, dtype=torch.uint8, device="cuda")) for _ in range(2)]
+    d_new = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    seen = 0
+    for _ in range(12):
+        _advance(w, g, 400)
+        g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP)
+        g.done_device(d_new.data_ptr())
+        g.synchronize()
+        three.reset_memory(d_new.data_ptr())
+        three.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP, B, out[0][0].data_ptr(), out[0][1].data_ptr())
+        three.act(out[0][0].data_ptr(), B, out[0][2].data_ptr(), seed=1)
+        one.predict_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP, B, out[1][0].data_ptr(),
+                           out[1][1].data_ptr(), out[1][2].data_ptr(), seed=1, reset_words=view)
+        three.synchronize(), one.synchronize()
+        for x, y in zip(out[0], out[1]):
+            assert torch.equal(x, y)
+        for b in range(B):
+            assert np.array_equal(three.get_memory(b)[0], one.get_memory(b)[0])
+        seen += int((d_new != 0).sum().item())
+    assert seen > 0  # (some games ended)

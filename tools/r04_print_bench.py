@@ -14,5 +14,8 @@ for f in sys.argv[1:]:
             i["k_step_K1_ms"], i["k_observe_ms"])
     if "policy" in d:
         p = d["policy"]
-        line += " | policy %.2f M agent-steps/s (%.4f ms; forward %.4f)" % (p["agent_steps_per_s"] / 1e6, p["ms_per_step"], p["forward_ms"]["default_init"])
+        line += " | policy %.2f M agent-steps/s (%.4f ms; forward %.4f; k_tail %.4f)" % (
+            p["agent_steps_per_s"] / 1e6, p["ms_per_step"], p["forward_ms"]["default_init"], p["kernels"]["k_tail"]["ms_per_forward"])
+        if "separate_calls" in p:
+            line += " separate calls %.2f M" % (p["separate_calls"]["agent_steps_per_s"] / 1e6)
     print(line)

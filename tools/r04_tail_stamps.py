@@ -5,13 +5,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["SF_LIBRARY_PATH"] = os.path.join(ROOT, "tools", "ab", "libsf_taildiag.so")
+os.environ["SF_LIBRARY_PATH"] = os.path.join(ROOT, "tools", "ab", os.environ.get("SF_TAIL_DIAG_LIB", "libsf_taildiag.so"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from strikeforce_amd import config, env, policy  # noqa: E402
 
-A = 4096
+A = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 w = config.baseline_workload("C3", arenas=A)
 g = env.ArenaBatch(w)
 g.reset(*w.seeds())
@@ -45,3 +45,21 @@ print("wave life (with the ResB loop x3): mean %.0f cycles, max %.0f" % (tot.mea
 for k in range(23):
     x = out[:, :, k].astype(np.float64)
     print("  %2d %-28s mean %7.0f   wave 0 %7.0f   max over waves (mean over workgroups) %7.0f" % (k, names[k], x.mean(), x[:, 0].mean(), x.max(axis=1).mean()))
+# per wave index: the tile phases, and where the wave ran (HW_ID, slot 23: wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13)
+hw = out[:, :, 23]
+print("wave:        " + " ".join("%6d" % i for i in range(16)))
+for k in (0, 4, 6, 8, 12, 16, 18):
+    print("phase %2d:    " % k + " ".join("%6.0f" % v for v in out[:, :, k].astype(np.float64).mean(axis=0)))
+print("SIMD (wg 0): " + " ".join("%6d" % ((int(v) >> 4) & 3) for v in hw[0]))
+print("SIMD (wg 1): " + " ".join("%6d" % ((int(v) >> 4) & 3) for v in hw[1]))
+print("SIMD (wg 9): " + " ".join("%6d" % ((int(v) >> 4) & 3) for v in hw[9]))
+cu = ((hw[:, 0] >> 8) & 15) | (((hw[:, 0] >> 12) & 1) << 4) | (((hw[:, 0] >> 13) & 7) << 5)
+print("workgroups per (SE, SH, CU) id seen by wave 0 [id: count], XCC not in HW_ID:", dict(zip(*np.unique(cu, return_counts=True))))
+s4 = np.zeros(4)
+n4 = np.zeros(4)
+for wg in range(out.shape[0]):
+    for wv in range(16):
+        s = (int(hw[wg, wv]) >> 4) & 3
+        s4[s] += out[wg, wv, 4]
+        n4[s] += 1
+print("gru0 tile phase by SIMD: mean cycles", (s4 / np.maximum(n4, 1)).round(0), "waves", n4)
