@@ -181,7 +181,9 @@ def cpu_baseline(workload_name):
 
 WORKLOAD_TEXT = {
     "C2": "BASELINE configs[1] (C2)", "C3": "BASELINE configs[2] (C3)", "C4": "BASELINE configs[3] (C4)",
-    "C5": "BASELINE configs[4] (C5)"}
+    "C5": "BASELINE configs[4] (C5)",
+    "NATIVEGAME": "the reference's own world (not a BASELINE config: gameplay.hpp:37's 3 x 30 x 100 map, a whole Timer game, "
+                  "pools of 1024 zombies / 512 exits — the large-pool kernel, tables in LDS)"}
 
 
 def describe_workload(name, arenas, cfg):
@@ -196,7 +198,7 @@ def other_configs(args, local, torch, config, env, skip):
     """The same throughput measurement (pre-roll, commands resident, K steps per launch, one GPU, 4096 arenas) on the
     other BASELINE configurations that run on a GPU; parity for all of them is in tests/."""
     out = {}
-    for name in ("C2", "C3", "C4", "C5"):
+    for name in ("C2", "C3", "C4", "C5", "NATIVEGAME"):
         if name == skip:
             continue
         w = config.baseline_workload(name, arenas=args.arenas, device=local)

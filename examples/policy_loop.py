@@ -26,19 +26,26 @@ stream = torch.cuda.Stream()
 torch.cuda.set_stream(stream)
 sim.set_stream(stream.cuda_stream), net.set_stream(stream.cuda_stream)
 sim.reset(*w.seeds())
-d_obs = torch.empty((agents, 32, 31, 31), dtype=torch.float32, device="cuda")
+CAP = 2048                                                   # list entries per agent (an observation has ~250 non-zero floats)
+d_keys = torch.zeros((agents, CAP), dtype=torch.int32, device="cuda")
+d_vals = torch.zeros((agents, CAP), dtype=torch.float32, device="cuda")
+d_counts = torch.zeros(agents, dtype=torch.int32, device="cuda")
+d_pov = torch.zeros((agents, 160), dtype=torch.float32, device="cuda")
+d_dense = torch.empty((agents, 32, 31, 31), dtype=torch.float32, device="cuda")  # rows only for lists that do not fit
 d_probs = torch.empty((agents, 9), dtype=torch.float32, device="cuda")
 d_value = torch.empty(agents, dtype=torch.float32, device="cuda")
 d_cmd = torch.zeros(agents, dtype=torch.uint8, device="cuda")
-d_new = torch.zeros(agents, dtype=torch.uint8, device="cuda")
+restarted = sim.done_view_device()                           # the games that just restarted, where the library keeps the flags
 t0 = time.perf_counter()
 for t in range(steps):
-    sim.observe_device_delta(d_obs.data_ptr())                                      # gameplay::bot()'s encoding (changes only)
-    net.forward(d_obs.data_ptr(), agents, d_probs.data_ptr(), d_value.data_ptr())   # AgentModel::forward
-    net.act(d_probs.data_ptr(), agents, d_cmd.data_ptr(), seed=1234)                # Agent::predict's sampling + update
-    sim.step_device(d_cmd.data_ptr(), 1)                                            # one tick of every arena
-    sim.done_device(d_new.data_ptr())                                               # games that just restarted ...
-    net.reset_memory(d_new.data_ptr())                                              # ... get a new Agent's memory
+    # gameplay::bot()'s encoding as the list of its non-zero floats (the dense form: observe_device + net.forward)
+    sim.observe_sparse_device(d_keys.data_ptr(), d_vals.data_ptr(), d_counts.data_ptr(), d_pov.data_ptr(), CAP)
+    sim.observe_overflow_device(d_counts.data_ptr(), CAP, d_dense.data_ptr(), d_pov.data_ptr())
+    # Agent::predict + update in one call: a new Agent's memory for restarted games, AgentModel::forward, the draw
+    # (the same as net.reset_memory / net.forward_sparse / net.act one after the other)
+    net.predict_sparse(d_keys.data_ptr(), d_vals.data_ptr(), d_counts.data_ptr(), d_pov.data_ptr(), CAP, agents, d_probs.data_ptr(),
+                       d_value.data_ptr(), d_cmd.data_ptr(), seed=1234, d_dense_ptr=d_dense.data_ptr(), reset_words=restarted)
+    sim.step_device(d_cmd.data_ptr(), 1)                     # one tick of every arena
 sim.synchronize()
 net.synchronize()
 dt = time.perf_counter() - t0

@@ -176,7 +176,8 @@ struct ObsSparse {
   float *pov;
   int cap;
 };
-__global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out, uint32_t *nzprev, int mode, ObsSparse sp) {
+// one agent's window (workgroup `bid` of the plain launch)
+static __device__ __forceinline__ void observe_agent(const Params &p, float *out, uint32_t *nzprev, int mode, const ObsSparse &sp, const unsigned bid) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ent[];  // [13][H] humans, [3][Z] zombies, [4][B] bullets
   __shared__ float rec[OBS_REC_MAX][SF_OBS_CHANNELS];
   __shared__ uint32_t occ[OBS_W2];
@@ -198,24 +199,24 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
   static_assert(offsetof(Tables, cons_items) == 0 && offsetof(Tables, der) == sizeof(int32_t) * 12,
                 "obs_cell_emit's tables must lead Tables");
   __shared__ uint32_t list_n, rec_n, spill_n;
-  const int a = (int)blockIdx.x / p.n_agents, g = (int)blockIdx.x % p.n_agents;
+  const int a = (int)bid / p.n_agents, g = (int)bid % p.n_agents;
   const int tid = (int)threadIdx.x;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  SF_GLOBAL float *o = gptr(out) + (size_t)blockIdx.x * SF_OBS_FLOATS;
+  SF_GLOBAL float *o = gptr(out) + (size_t)bid * SF_OBS_FLOATS;
   SF_GLOBAL f32x4 *o4 = reinterpret_cast<SF_GLOBAL f32x4 *>(o);  // 30752 floats = 7688 x 16 B, 16-B aligned
   // ---- prologue --------------------------------------------------------------------------------------------
   const uint32_t hf = gptr(p.hum)[((size_t)HW_FLAGS * p.A + a) * p.H + g];
   const uint32_t center = gptr(p.hum)[((size_t)HW_POS * p.A + a) * p.H + g];
-  SF_GLOBAL uint32_t *old = nzprev ? gptr(nzprev) + (size_t)blockIdx.x * OBS_W2 : nullptr;
+  SF_GLOBAL uint32_t *old = nzprev ? gptr(nzprev) + (size_t)bid * OBS_W2 : nullptr;
   const bool redo = mode == 4;
   if (mode == 4) {  // sf_observe_overflow_device: the plain dense write, but only for the agents whose list did not fit
-    const uint32_t c = gptr(sp.counts)[blockIdx.x];
+    const uint32_t c = gptr(sp.counts)[bid];
     if (!(c == 0xffffffffu || c > (uint32_t)sp.cap)) return;  // (uniform over the workgroup)
     mode = 0;
   }
   if (mode == 3 && (hf & (HF_ALIVE | HF_CTRL)) != (HF_ALIVE | HF_CTRL)) {  // no observer: an empty list
-    if (tid == 0) gptr(sp.counts)[blockIdx.x] = 0u;
-    if (tid < 5 * SF_OBS_CHANNELS) gptr(sp.pov)[(size_t)blockIdx.x * (5 * SF_OBS_CHANNELS) + tid] = 0.f;
+    if (tid == 0) gptr(sp.counts)[bid] = 0u;
+    if (tid < 5 * SF_OBS_CHANNELS) gptr(sp.pov)[(size_t)bid * (5 * SF_OBS_CHANNELS) + tid] = 0.f;
     return;
   }
   if ((hf & (HF_ALIVE | HF_CTRL)) != (HF_ALIVE | HF_CTRL)) {  // no observer: all zero (uniform over the workgroup)
@@ -388,8 +389,8 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
       if (q < (tid >> 6)) pos += wave_tot[q];
       total += wave_tot[q];
     }
-    SF_GLOBAL uint32_t *kd = gptr(sp.keys) + (size_t)blockIdx.x * (size_t)sp.cap;
-    SF_GLOBAL float *vd = gptr(sp.vals) + (size_t)blockIdx.x * (size_t)sp.cap;
+    SF_GLOBAL uint32_t *kd = gptr(sp.keys) + (size_t)bid * (size_t)sp.cap;
+    SF_GLOBAL float *vd = gptr(sp.vals) + (size_t)bid * (size_t)sp.cap;
     auto emit = [&](uint32_t e, uint32_t idx) {  // entry e of the list: dense index -> key, value
       const uint32_t k = idx / (uint32_t)OBS_W2, w = idx - k * (uint32_t)OBS_W2;
       const uint32_t y = w / (uint32_t)SF_OBS_WINDOW, x = w - y * (uint32_t)SF_OBS_WINDOW;
@@ -420,13 +421,13 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
           ++pos;
         }
     }
-    if (tid == 0) gptr(sp.counts)[blockIdx.x] = spill_n ? 0xffffffffu : total;
+    if (tid == 0) gptr(sp.counts)[bid] = spill_n ? 0xffffffffu : total;
     if (tid < 5 * SF_OBS_CHANNELS) {  // the network's pov: cells (-1,0) (0,-1) (0,0) (0,1) (1,0) around the centre, Modules.hpp:114-121
       const int cell = tid >> 5, ch = tid & 31;
       const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0, dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
       const uint32_t w = (uint32_t)((SF_OBS_WINDOW / 2 + dy) * SF_OBS_WINDOW + (SF_OBS_WINDOW / 2 + dx));
       const uint32_t bit = (uint32_t)ch * (uint32_t)OBS_W2 + w;
-      gptr(sp.pov)[(size_t)blockIdx.x * (5 * SF_OBS_CHANNELS) + tid] = ((nzmap[bit >> 5] >> (bit & 31u)) & 1u) ? rec[slot[w]][ch] : 0.f;
+      gptr(sp.pov)[(size_t)bid * (5 * SF_OBS_CHANNELS) + tid] = ((nzmap[bit >> 5] >> (bit & 31u)) & 1u) ? rec[slot[w]][ch] : 0.f;
     }
     return;
   }
@@ -473,8 +474,30 @@ __global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out
       const int cell = tid >> 5, ch = tid & 31;
       const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0, dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
       const int w = (SF_OBS_WINDOW / 2 + dy) * SF_OBS_WINDOW + (SF_OBS_WINDOW / 2 + dx);
-      gptr(sp.pov)[(size_t)blockIdx.x * (5 * SF_OBS_CHANNELS) + tid] = o[ch * OBS_W2 + w];
+      gptr(sp.pov)[(size_t)bid * (5 * SF_OBS_CHANNELS) + tid] = o[ch * OBS_W2 + w];
     }
+  }
+}
+
+__global__ __launch_bounds__(OBS_THREADS, 6) void k_observe(Params p, float *out, uint32_t *nzprev, int mode, ObsSparse sp) {
+  observe_agent(p, out, nzprev, mode, sp, blockIdx.x);
+}
+// sf_observe_overflow_device: a few workgroups walk the agents and redo (mode 4) those whose list did not fit — none, normally,
+// and then the launch is one load per thread (as one workgroup per agent the idle launch cost 4 us of a 230 us loop).  A kernel
+// of its own: two copies of the window code in one kernel spilled registers.
+__global__ __launch_bounds__(OBS_THREADS) void k_observe_redo(Params p, float *out, ObsSparse sp) {
+  const unsigned n = (unsigned)(p.A * p.n_agents);
+  auto over = [&](unsigned b) {
+    const uint32_t c = gptr(sp.counts)[b];
+    return c == 0xffffffffu || c > (uint32_t)sp.cap;
+  };
+  bool mine = false;
+  for (unsigned b = blockIdx.x + threadIdx.x * gridDim.x; b < n; b += OBS_THREADS * gridDim.x) mine = mine || over(b);
+  if (!__syncthreads_or(mine)) return;
+  for (unsigned b = blockIdx.x; b < n; b += gridDim.x) {
+    if (!over(b)) continue;  // (uniform over the workgroup)
+    observe_agent(p, out, nullptr, 4, sp, b);
+    __syncthreads();  // the next agent takes over the workgroup's LDS
   }
 }
 
@@ -972,9 +995,9 @@ struct HipRT {
   int launch_observe_overflow(const Params &p, const uint32_t *counts, int cap, float *dense, float *pov) {
     SF_HIP(hipSetDevice(device));
     const int n = p.A * p.n_agents;
-    hipLaunchKernelGGL(k_observe, dim3((unsigned)n), dim3(OBS_THREADS),
+    hipLaunchKernelGGL(k_observe_redo, dim3((unsigned)(n < 512 ? n : 512)), dim3(OBS_THREADS),
                        obs_lds_bytes(p),
-                       stream, p, dense, (uint32_t *)nullptr, 4,
+                       stream, p, dense,
                        ObsSparse{nullptr, nullptr, const_cast<uint32_t *>(counts), pov, cap});
     SF_HIP(hipGetLastError());
     return SF_OK;

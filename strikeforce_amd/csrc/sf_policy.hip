@@ -1016,6 +1016,14 @@ __global__ __launch_bounds__(FD_T) void k_feat_dense(const float *__restrict__ o
       while (b < agents && !(li.counts[b] > (uint32_t)C0_LCAP || li.counts[b] > (uint32_t)li.cap)) b += (int)gridDim.x;
     return b;
   };
+  if (li.counts) {
+    // the launch behind k_feat_list is idle when every list fitted: each thread looks at one of this workgroup's agents
+    // (one load each, all in flight together — walking them with nxt() is a chain of dependent loads: 7 us of a 230 us loop)
+    bool mine = false;
+    for (int b = (int)blockIdx.x + t * (int)gridDim.x; b < agents; b += FD_T * (int)gridDim.x)
+      mine = mine || li.counts[b] > (uint32_t)C0_LCAP || li.counts[b] > (uint32_t)li.cap;
+    if (!__syncthreads_or(mine)) return;
+  }
   constexpr int NIT = (FD_SEG + 63) / 64;  // 31 floats per lane
   const float *Fl = F + 4 * (l < HID / 4 ? l : 0);
   for (int b = nxt((int)blockIdx.x); b < agents; b = nxt(b + (int)gridDim.x)) {
@@ -2122,7 +2130,8 @@ static int forward(Policy *p, const float *d_obs, int agents, float *d_probs, fl
       hipLaunchKernelGGL(k_feat_list, dim3((unsigned)agents), dim3(64), 0, st, p->fold, p->feat, agents, *li);
       if (e0) SFP_HIP(hipEventRecord(e0, st));
       if (d_obs)  // redo the agents whose list did not fit from their dense observation (none, normally: the launch is idle)
-        hipLaunchKernelGGL(k_feat_dense, fd_grid, dim3(FD_T), 0, st, d_obs, p->fold, p->feat, agents, *li);
+        hipLaunchKernelGGL(k_feat_dense, dim3((unsigned)(agents < p->sk_blocks ? agents : p->sk_blocks)), dim3(FD_T), 0, st, d_obs, p->fold,
+                           p->feat, agents, *li);
     } else {
       hipLaunchKernelGGL(k_feat_dense, fd_grid, dim3(FD_T), 0, st, d_obs, p->fold, p->feat, agents, C0List{});
       if (e0) SFP_HIP(hipEventRecord(e0, st));

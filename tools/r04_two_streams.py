@@ -59,16 +59,15 @@ def interactive(P):
 
 
 def closed(P):
+    views = [g.done_view_device() for g, *_ in P]
+
     def body():
-        for g, n, _d, b, pb, _st in P:
+        for (g, n, _d, b, pb, _st), view in zip(P, views):
             g.observe_sparse_device(b["keys"].data_ptr(), b["vals"].data_ptr(), b["cnt"].data_ptr(), b["pov"].data_ptr(), CAP)
             g.observe_overflow_device(b["cnt"].data_ptr(), CAP, b["dense"].data_ptr(), b["pov"].data_ptr())
-            pb.forward_sparse(b["keys"].data_ptr(), b["vals"].data_ptr(), b["cnt"].data_ptr(), b["pov"].data_ptr(), CAP, n, b["probs"].data_ptr(),
-                              b["value"].data_ptr(), d_dense_ptr=b["dense"].data_ptr())
-            pb.act(b["probs"].data_ptr(), n, b["cmd"].data_ptr(), seed=0)
+            pb.predict_sparse(b["keys"].data_ptr(), b["vals"].data_ptr(), b["cnt"].data_ptr(), b["pov"].data_ptr(), CAP, n, b["probs"].data_ptr(),
+                              b["value"].data_ptr(), b["cmd"].data_ptr(), seed=0, d_dense_ptr=b["dense"].data_ptr(), reset_words=view)
             g.step_device(b["cmd"].data_ptr(), 1)
-            g.done_device(b["new"].data_ptr())
-            pb.reset_memory(b["new"].data_ptr())
     for _ in range(3):
         body()
     torch.cuda.synchronize()
@@ -79,7 +78,7 @@ def closed(P):
     return (time.perf_counter() - t0) / 20
 
 
-for S in (1, 2, 4, 8):
+for S in ((1, 2, 4, 8) if "--closed-only" not in sys.argv else ()):
     P = parts(S, False)
     dt = interactive(P)
     print("interactive, list observation, %d part(s): %.4f ms per step of %d arenas = %.1f M env-steps/s" % (S, dt * 1e3, TOTAL, TOTAL / dt / 1e6), flush=True)
