@@ -50,8 +50,9 @@ def load_library():
         L.sf_observe_overflow_device.restype = C.c_int
         L.sf_results_device.argtypes = [vp, vp]
         L.sf_done_device.argtypes = [vp, vp]
-        L.sf_done_view_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-        L.sf_done_view_device.restype = C.c_int
+        if hasattr(L, "sf_done_view_device"):  # (A/B runs against older builds of the library, tools/ab.sh)
+            L.sf_done_view_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+            L.sf_done_view_device.restype = C.c_int
         L.sf_set_stream.argtypes = [vp, vp]
         L.sf_synchronize.argtypes = [vp]
         L.sf_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]

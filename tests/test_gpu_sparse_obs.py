@@ -304,3 +304,52 @@ def test_the_done_view_is_what_sf_done_device_copies():
             assert np.array_equal(three.get_memory(b)[0], one.get_memory(b)[0])
         seen += int((d_new != 0).sum().item())
     assert seen > 0  # (some games ended)
+
+
+def test_the_closed_loop_through_predict_equals_the_separate_calls_at_bench_size():
+    """bench.py's `policy` loop both ways on configs[2] at 4096 arenas, 150 steps from the same start: five launches per
+    step (sf_policy_predict_sparse reading sf_done_view_device's flags) against eight (forward, act, step, sf_done_device,
+    sf_policy_reset_memory).  The two worlds stay digest-identical — every command, hence every draw, hence every restart
+    was the same — and so do the networks' memories; games end and restart on the way."""
+    A, STEPS = 4096, 150
+    worlds = []
+    for _ in range(2):
+        w = config.baseline_workload("C3", arenas=A)
+        g = env.ArenaBatch(w)
+        g.reset(*w.seeds())
+        _advance(w, g, 300)
+        worlds.append((w, g, policy.PolicyBatch(policy.init_parameters(seed=0), A), _bufs(A),
+                       (torch.zeros((A, 9), device="cuda"), torch.zeros(A, device="cuda"), torch.zeros(A, dtype=torch.uint8, device="cuda"))))
+    d_fb = torch.empty((A, 32, 31, 31), dtype=torch.float32, device="cuda")
+    d_new = torch.zeros(A, dtype=torch.uint8, device="cuda")
+    view = worlds[0][1].done_view_device()
+    restarted = 0
+    for step in range(STEPS):
+        for which, (w, g, pb, (keys, vals, counts, pov), (probs, value, cmd)) in enumerate(worlds):
+            g.observe_sparse_device(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP)
+            g.observe_overflow_device(counts.data_ptr(), CAP, d_fb.data_ptr(), pov.data_ptr())
+            if which == 0:
+                pb.predict_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP, A, probs.data_ptr(), value.data_ptr(),
+                                  cmd.data_ptr(), seed=3, d_dense_ptr=d_fb.data_ptr(), reset_words=view)
+                g.step_device(cmd.data_ptr(), 1)
+            else:
+                pb.forward_sparse(keys.data_ptr(), vals.data_ptr(), counts.data_ptr(), pov.data_ptr(), CAP, A, probs.data_ptr(), value.data_ptr(),
+                                  d_dense_ptr=d_fb.data_ptr())
+                pb.act(probs.data_ptr(), A, cmd.data_ptr(), seed=3)
+                g.step_device(cmd.data_ptr(), 1)
+                g.done_device(d_new.data_ptr())
+                pb.reset_memory(d_new.data_ptr())
+                g.synchronize()
+                restarted += int((d_new != 0).sum().item())
+        if step % 50 == 49 or step == STEPS - 1:
+            for (_, g, pb, _, _) in worlds:
+                g.synchronize(), pb.synchronize()
+            assert np.array_equal(worlds[0][1].digest(), worlds[1][1].digest()), "step %d" % step
+            assert torch.equal(worlds[0][4][0], worlds[1][4][0]) and torch.equal(worlds[0][4][2], worlds[1][4][2])
+    for b in range(0, A, 97):
+        h0, a0 = worlds[0][2].get_memory(b)
+        h1, a1 = worlds[1][2].get_memory(b)
+        # (the separate calls have already reset the restarted agents' stored memory; predict does that when it next runs)
+        if not bool(d_new[b].item()):
+            assert np.array_equal(h0, h1) and np.array_equal(a0, a1)
+    assert restarted > 20
