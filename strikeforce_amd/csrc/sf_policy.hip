@@ -1483,44 +1483,6 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
   const int a_raw = blockIdx.x * TL_R + w;
   const bool valid = a_raw < t.agents;
   const int a = valid ? a_raw : t.agents - 1;  // a ragged last workgroup computes its missing rows on the last agent, stores nothing
-  // a restarted game's agent is a new Agent (gameplay.hpp:481): zero memory, "no action" as its last action
-  bool fresh = false;  // (uniform over the wave)
-  if (t.reset_mask) fresh = t.reset_mask[a] != 0;
-  if (t.reset_words) fresh = fresh || t.reset_words[(size_t)(a / t.reset_group) * (size_t)t.reset_stride] != 0;
-  fresh = __builtin_amdgcn_readfirstlane((int)fresh) != 0;
-  // ---- conv3's input (act2 row = 9 pixels x 160 channels, the K order of the permuted weight) and h0
-  {
-    if (!t.feat) {
-      const f32x4 *src = reinterpret_cast<const f32x4 *>(t.act2 + (size_t)a * (9 * HID));
-      f32x4 *dst = reinterpret_cast<f32x4 *>(tl + TL_A + w * TL_LDX);
-      for (int i = l; i < 9 * HID / 4; i += 64) dst[i] = src[i];
-    }
-    row_store(tl + TL_B1 + w * TL_LD, l, fresh ? Row3{} : row_load(t.h[0] + (size_t)a * HID, l));
-  }
-  // fetched now, used after gru0: the agent's pov (5 cells x 32 channels around the centre of the observation, then the
-  // action one-hot) and its h1 — 160 scattered HBM lines, issued together with conv3's input
-  {
-    const float *op = t.obs + (size_t)a * OBS_F;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int e = l + 64 * i;
-      float v = 0.f;
-      if (e < 5 * OBS_C) {
-        if (t.pov) {
-          v = t.pov[(size_t)a * (5 * OBS_C) + e];
-        } else {
-          const int cell = e >> 5, ch = e & 31;
-          const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0;
-          const int dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
-          v = op[(size_t)ch * OBS_W * OBS_W + (OBS_W / 2 + dy) * OBS_W + (OBS_W / 2 + dx)];
-        }
-      } else if (e < POV) {
-        v = fresh ? (e == 5 * OBS_C ? 1.f : 0.f) : t.action_input[(size_t)a * ACT + (e - 5 * OBS_C)];
-      }
-      tl[TL_PV + w * TL_LDP + e] = v;
-    }
-    row_store(tl + TL_H1 + w * TL_LD, l, fresh ? Row3{} : row_load(t.h[1] + (size_t)a * HID, l));
-  }
   // the weight stream (see ts_tile160): where each of this wave's tiles lives
   TsBuf b0 = {}, b1 = {};
   auto gru_wp = [&](int g, int tt) {
@@ -1531,9 +1493,55 @@ __global__ __launch_bounds__(TL_T) void k_tail(TailArgs t) {
     const int hd = tt >= HID / 16, n0 = 16 * (tt - hd * (HID / 16));
     return ts_wp(t.res_w[hd][i], HID, n0, l);
   };
-  if (t.feat) {  // folded form: gru0's first tile is this wave's first, and feat_n is a row of its own agent     :108
-    const Row3 fr = row_load(t.feat + (size_t)a * HID, l);
-    b0 = ts_issue<5>(b0, gru_wp(0, w), 0);
+  // ---- the prologue's global loads: the restart flags, h0, h1, the agent's pov (5 cells x 32 channels around the centre of
+  // the observation, then the action one-hot), its feature row, the first weights.  All of them are issued before the
+  // first is waited for: every load is unconditional, from an address that is valid whatever the options (written behind
+  // uniform branches the compiler kept them in program order, a wait after each — eight round trips, 7 k cycles of the
+  // kernel's start).
+  const uint8_t *fmp = t.reset_mask ? t.reset_mask + a : reinterpret_cast<const uint8_t *>(t.h[0]);
+  const int32_t *fwp = t.reset_words ? t.reset_words + (size_t)(a / t.reset_group) * (size_t)t.reset_stride : reinterpret_cast<const int32_t *>(t.h[0]);
+  const uint8_t fm = *fmp;
+  const int32_t fw = *fwp;
+  Row3 h0 = row_load(t.h[0] + (size_t)a * HID, l), h1 = row_load(t.h[1] + (size_t)a * HID, l);
+  float pvv[3];
+  {
+    const float *op = t.obs + (size_t)a * OBS_F;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = l + 64 * i;
+      const float *src = t.action_input + (size_t)a * ACT;  // (lanes past the row: any valid address, the value is dropped)
+      if (e < 5 * OBS_C) {
+        const int cell = e >> 5, ch = e & 31;
+        const int dy = (cell == 0) ? -1 : (cell == 4) ? 1 : 0;
+        const int dx = (cell == 1) ? -1 : (cell == 3) ? 1 : 0;
+        src = t.pov ? t.pov + (size_t)a * (5 * OBS_C) + e : op + (size_t)ch * OBS_W * OBS_W + (OBS_W / 2 + dy) * OBS_W + (OBS_W / 2 + dx);
+      } else if (e < POV) {
+        src += e - 5 * OBS_C;
+      }
+      pvv[i] = *src;
+    }
+  }
+  const Row3 fr = row_load((t.feat ? t.feat : t.h[0]) + (size_t)a * HID, l);
+  if (t.feat) b0 = ts_issue<5>(b0, gru_wp(0, w), 0);  // folded form: gru0's first tile is this wave's first
+  // a restarted game's agent is a new Agent (gameplay.hpp:481): zero memory, "no action" as its last action
+  const bool fresh = __builtin_amdgcn_readfirstlane((int)((t.reset_mask && fm != 0) || (t.reset_words && fw != 0))) != 0;  // (uniform over the wave)
+  if (fresh) h0 = Row3{}, h1 = Row3{};
+  if (!t.feat) {  // conv3's input (act2 row = 9 pixels x 160 channels, the K order of the permuted weight)
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(t.act2 + (size_t)a * (9 * HID));
+    f32x4 *dst = reinterpret_cast<f32x4 *>(tl + TL_A + w * TL_LDX);
+    for (int i = l; i < 9 * HID / 4; i += 64) dst[i] = src[i];
+  }
+  row_store(tl + TL_B1 + w * TL_LD, l, h0);
+  row_store(tl + TL_H1 + w * TL_LD, l, h1);  // (used after gru0)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = l + 64 * i;
+    float v = 0.f;
+    if (e < 5 * OBS_C) v = pvv[i];
+    else if (e < POV) v = fresh ? (e == 5 * OBS_C ? 1.f : 0.f) : pvv[i];
+    tl[TL_PV + w * TL_LDP + e] = v;
+  }
+  if (t.feat) {  // feat_n is a row of the wave's own agent                                                     :108
     row_store(tl + TL_B0 + w * TL_LD, l, row_norm(fr));
     TL_STAMP(0);
     TL_STAMP(1);

@@ -62,3 +62,14 @@ def test_cpp_adapter_example_matches_python_and_oracle(tmp_path):
     ended_orc = _drive(o, arenas, steps)
     assert dig_cpp == [int(x) for x in g.digest()] == [int(x) for x in o.digest()]
     assert ended_cpp == ended_gpu == ended_orc
+
+
+@pytest.mark.gpu
+def test_the_python_closed_loop_example_runs():
+    """examples/policy_loop.py (list observation -> sf_policy_predict_sparse -> step, everything on the device)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "policy_loop.py"), "64", "30"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "agent-steps/s" in out.stdout
