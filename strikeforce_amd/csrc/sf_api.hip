@@ -711,37 +711,40 @@ static __device__ __forceinline__ void observe_list_wave(const Params &p, const 
   // ---- 3: the list, in scan order: channel, then window cell ------------------------------------------------------
   auto mask_of = [&](uint32_t s) { return s < (uint32_t)OBS_CLASS_RECS ? L.cmask[s] : L.recmask[s - OBS_CLASS_RECS]; };
   auto value_of = [&](uint32_t s, uint32_t k) { return s < (uint32_t)OBS_CLASS_RECS ? L.crec[s][k] : rec[(s - OBS_CLASS_RECS) * OL_STRIDE + k]; };
-  // the compact cells, 64 per pass: which channels does a pass hold at all
+  // the compact cells, 64 per pass: what a lane needs of its cell in each pass stays in registers for the whole channel
+  // loop (record, channel mask, the key's position bits), and which channels a pass holds at all
   constexpr int CP_MAX = OL_CELLS / 64;  // 10
   const int npass = (int)((ncell + 63u) / 64u);
   uint32_t cpm = 0u;  // lane i < npass: the OR of pass i's channel masks
-  for (int cp = 0; cp < npass; ++cp) {
+  uint32_t pm[CP_MAX], ps[CP_MAX], pkey[CP_MAX];
+#pragma unroll
+  for (int cp = 0; cp < CP_MAX; ++cp) {
+    pm[cp] = 0u, ps[cp] = 0u, pkey[cp] = 0u;
+    if (cp >= npass) continue;  // (uniform)
     const uint32_t c = (uint32_t)cp * 64u + (uint32_t)l;
-    const uint32_t m = c < ncell ? mask_of((uint32_t)L.cell[c] >> 10) : 0u;
-    const uint32_t o = wave_or(m);
+    if (c < ncell) {
+      const uint32_t ent = (uint32_t)L.cell[c], w = ent & 1023u;
+      const uint32_t y = w / (uint32_t)SF_OBS_WINDOW, x = w - y * (uint32_t)SF_OBS_WINDOW;
+      ps[cp] = ent >> 10, pm[cp] = mask_of(ps[cp]), pkey[cp] = (y << 9) | (x << 14);
+    }
+    const uint32_t o = wave_or(pm[cp]);
     cpm = l == cp ? o : cpm;
   }
-  (void)CP_MAX;
   OL_STAMP(5);
   SF_GLOBAL uint32_t *kd = gptr(sp.keys) + (size_t)agent * (size_t)sp.cap;
   SF_GLOBAL float *vd = gptr(sp.vals) + (size_t)agent * (size_t)sp.cap;
   uint32_t base = 0u;
   for (uint32_t chans = wave_or(cpm); chans; chans &= chans - 1u) {  // the channels the window holds at all, ascending
     const uint32_t k = (uint32_t)__builtin_ctz(chans);
-    uint32_t passes = (uint32_t)__builtin_amdgcn_ballot_w64(((cpm >> k) & 1u) != 0u);  // which passes hold channel k
-    while (passes) {
-      const int cp = __builtin_ctz(passes);
-      passes &= passes - 1u;
-      const uint32_t c = (uint32_t)cp * 64u + (uint32_t)l;
-      const uint32_t ent = c < ncell ? (uint32_t)L.cell[c] : 0u, s = ent >> 10, w = ent & 1023u;
-      const bool has = c < ncell && ((mask_of(s) >> k) & 1u) != 0u;
+    const uint32_t passes = (uint32_t)__builtin_amdgcn_ballot_w64(((cpm >> k) & 1u) != 0u);  // which passes hold channel k
+#pragma unroll
+    for (int cp = 0; cp < CP_MAX; ++cp) {
+      if (!((passes >> cp) & 1u)) continue;  // (uniform)
+      const bool has = ((pm[cp] >> k) & 1u) != 0u;
       const uint64_t bal = __builtin_amdgcn_ballot_w64(has);
       if (has) {
         const uint32_t e = base + rank_below(bal);
-        if (e < (uint32_t)sp.cap) {
-          const uint32_t y = w / (uint32_t)SF_OBS_WINDOW, x = w - y * (uint32_t)SF_OBS_WINDOW;
-          kd[e] = (k * 9u) | (y << 9) | (x << 14), vd[e] = value_of(s, k);
-        }
+        if (e < (uint32_t)sp.cap) kd[e] = (k * 9u) | pkey[cp], vd[e] = value_of(ps[cp], k);
       }
       base += (uint32_t)__builtin_popcountll(bal);
     }
