@@ -150,17 +150,18 @@ constexpr uint32_t OBS_NOREC = 255u;
 //   pass 4    stream the output: each lane produces 4 consecutive floats by looking up cell -> record
 // record shared by every window cell with this flag byte and nothing on it, or -1
 static __device__ __forceinline__ int obs_class_of(uint32_t fl) {
-  switch (fl) {
-    case SF_CELL_WALL: return 0;
-    case SF_CELL_PIN_UP: return 1;
-    case SF_CELL_PIN_DN: return 2;
-    case SF_CELL_POUT: return 3;
-    case SF_CELL_CHEST | (0u << SF_CELL_CONS_SHIFT): return 4;
-    case SF_CELL_CHEST | (1u << SF_CELL_CONS_SHIFT): return 5;
-    case SF_CELL_CHEST | (2u << SF_CELL_CONS_SHIFT): return 6;
-    case SF_CELL_CHEST | (3u << SF_CELL_CONS_SHIFT): return 7;
-  }
-  return -1;
+  // (a chain of selects: as a `switch` this became a tree of divergent branches, ~200 scalar mask instructions per use —
+  // most of k_observe_list's classify phase)
+  int c = -1;
+  c = fl == SF_CELL_WALL ? 0 : c;
+  c = fl == SF_CELL_PIN_UP ? 1 : c;
+  c = fl == SF_CELL_PIN_DN ? 2 : c;
+  c = fl == SF_CELL_POUT ? 3 : c;
+  c = fl == (SF_CELL_CHEST | (0u << SF_CELL_CONS_SHIFT)) ? 4 : c;
+  c = fl == (SF_CELL_CHEST | (1u << SF_CELL_CONS_SHIFT)) ? 5 : c;
+  c = fl == (SF_CELL_CHEST | (2u << SF_CELL_CONS_SHIFT)) ? 6 : c;
+  c = fl == (SF_CELL_CHEST | (3u << SF_CELL_CONS_SHIFT)) ? 7 : c;
+  return c;
 }
 // mode 0: plain.  mode 1: plain + record which floats are non-zero in nzprev.  mode 2 (sf_observe_device_delta): the
 // buffer still holds what the previous call left, nzprev says which floats of it are non-zero: only 16-byte pieces
@@ -599,37 +600,50 @@ static __device__ __forceinline__ void observe_list_wave(const Params &p, const 
   }
   OL_STAMP(0);
   // ---- 1: occupant words -------------------------------------------------------------------------------------
-  for (int w4 = l; w4 < (OBS_W2 + 3) / 4; w4 += 64) reinterpret_cast<u32x4 *>(occ)[w4] = (u32x4)(0u);
-  if (l < OBS_CLASS_RECS) L.cmask[l] = gptr(p.tab)->class_mask[l];
-  if (l == 0) L.powq_n = 0u;
-  for (int t = l; t < OBS_CLASS_RECS * SF_OBS_CHANNELS; t += 64) L.crec[t >> 5][t & 31] = gptr(p.tab)->class_rec[t >> 5][t & 31];
+  // (every global load of this phase first, into registers: class records, the constant table, the first 64 slots of each
+  // entity table — written one by one, each with its LDS store or atomic behind it, they were ten round trips in a row)
+  const ObsView v(p, a);  // entity tables where they lie: a window holds ~20 of them
+  const uint32_t cm_ld = l < OBS_CLASS_RECS ? gptr(p.tab)->class_mask[l] : 0u;
+  float cr_ld[OBS_CLASS_RECS * SF_OBS_CHANNELS / 64];
+#pragma unroll
+  for (int q = 0; q < OBS_CLASS_RECS * SF_OBS_CHANNELS / 64; ++q) {
+    const int t = l + 64 * q;
+    cr_ld[q] = gptr(p.tab)->class_rec[t >> 5][t & 31];
+  }
   // the host-built constant table (the reference's libm): obs_map_fast.  One entry per lane, read by v_readlane below
   const float t_in = l < 16 ? gptr(p.tab)->obs_in[l] : 0.f, t_out = l < 16 ? gptr(p.tab)->obs_out[l] : 0.f;
   const int t_n = gptr(p.tab)->obs_n;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const ObsView v(p, a);  // entity tables where they lie: a window holds ~20 of them
-  if (l < p.H) {
-    if (v.hum(HW_FLAGS, l) & HF_OCC) {
-      const int s = obs_window_slot(v.hum(HW_POS, l), center);
-      if (s >= 0) atomicOr(&occ[s], (uint32_t)(l + 1));
-    }
-  }
   // (large pools: only the words of the zombie table that are in use, sf_core.hpp ZL)
   int zlim = p.Z;
   if (large_pools(p.Z, p.P)) {
     const int used = 64 * (int)gptr(p.scal)[(size_t)a * SC_WORDS + SC_ZWN];
     zlim = used < p.Z ? used : p.Z;
   }
+  const uint32_t h_fl = l < p.H ? v.hum(HW_FLAGS, l) : 0u, h_pos = l < p.H ? v.hum(HW_POS, l) : 0u;
+  const uint32_t z_first = l < zlim ? v.zom(ZW_POS, l) : 0u, b_first = l < p.B ? v.bul(BW_A, l) : 0u;
+  for (int w4 = l; w4 < (OBS_W2 + 3) / 4; w4 += 64) reinterpret_cast<u32x4 *>(occ)[w4] = (u32x4)(0u);
+  if (l < OBS_CLASS_RECS) L.cmask[l] = cm_ld;
+  if (l == 0) L.powq_n = 0u;
+#pragma unroll
+  for (int q = 0; q < OBS_CLASS_RECS * SF_OBS_CHANNELS / 64; ++q) {
+    const int t = l + 64 * q;
+    L.crec[t >> 5][t & 31] = cr_ld[q];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (h_fl & HF_OCC) {
+    const int s = obs_window_slot(h_pos, center);
+    if (s >= 0) atomicOr(&occ[s], (uint32_t)(l + 1));
+  }
   for (int z = l; z < zlim; z += 64) {
-    const uint32_t zp = v.zom(ZW_POS, z);
+    const uint32_t zp = z < 64 ? z_first : v.zom(ZW_POS, z);
     if (zp & ZF_ALIVE) {
       const int s = obs_window_slot(zp & POS_MASK, center);
       if (s >= 0) atomicOr(&occ[s], (uint32_t)(z + 1) << OCC_Z_SH);
     }
   }
   for (int b = l; b < p.B; b += 64) {
-    const uint32_t ba = v.bul(BW_A, b);
+    const uint32_t ba = b < 64 ? b_first : v.bul(BW_A, b);
     if (ba & BA_REF) {
       const int s = obs_window_slot(ba & POS_MASK, center);
       if (s >= 0) atomicOr(&occ[s], (uint32_t)(b + 1) << OCC_B_SH);
