@@ -335,9 +335,36 @@ struct WaveGfx950 {
   }
 
   // flag plane <-> LDS, 16 B per lane per pass (nbytes is a multiple of 16)
+  // (four loads in flight before the first LDS store: written one by one, each copy waited for its own load —
+  // a 4 KB plane was four round trips in a row)
   static SF_DEV void copy_g2l(uint8_t *lds, const uint8_t *g, uint32_t nbytes) {
-    for (uint32_t off = lane() * 16u; off < nbytes; off += 64u * 16u)
-      *reinterpret_cast<u32x4 *>(lds + off) = *reinterpret_cast<const SF_GLOBAL u32x4 *>(gptr(g) + off);
+    for (uint32_t base = 0u; base < nbytes; base += 4u * 1024u) {
+      G2L<4> q;
+      const uint32_t n = nbytes - base < 4u * 1024u ? nbytes - base : 4u * 1024u;
+      g2l_issue(q, g + base, n);
+      g2l_store(q, lds + base, n);
+    }
+  }
+  // the same in two halves, for the caller that has other loads to issue in between: up to U KB, U loads per lane
+  template <int U>
+  struct G2L {
+    u32x4 r[U];
+  };
+  template <int U>
+  static SF_DEV void g2l_issue(G2L<U> &q, const uint8_t *g, uint32_t nbytes) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const uint32_t off = (uint32_t)i * 1024u + lane() * 16u;
+      q.r[i] = off < nbytes ? *reinterpret_cast<const SF_GLOBAL u32x4 *>(gptr(g) + off) : (u32x4)(0u);
+    }
+  }
+  template <int U>
+  static SF_DEV void g2l_store(const G2L<U> &q, uint8_t *lds, uint32_t nbytes) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const uint32_t off = (uint32_t)i * 1024u + lane() * 16u;
+      if (off < nbytes) *reinterpret_cast<u32x4 *>(lds + off) = q.r[i];
+    }
     __builtin_amdgcn_wave_barrier();
   }
   static SF_DEV void copy_l2g(uint8_t *g, const uint8_t *lds, uint32_t nbytes) {

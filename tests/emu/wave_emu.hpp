@@ -349,6 +349,15 @@ struct WaveEmu {
       if ((pred.m >> i) & 1ull) base[idx.v[i]] = val.v[i];
   }
   static void copy_g2l(uint8_t *lds, const uint8_t *g, uint32_t n) { memcpy(lds, g, n); }
+  // the copy in two halves (wave_gfx950.hpp: loads first, LDS stores later); here the source is read at the store
+  template <int U>
+  struct G2L {
+    const uint8_t *g = nullptr;
+  };
+  template <int U>
+  static void g2l_issue(G2L<U> &q, const uint8_t *g, uint32_t) { q.g = g; }
+  template <int U>
+  static void g2l_store(const G2L<U> &q, uint8_t *lds, uint32_t n) { memcpy(lds, q.g, n); }
   static void copy_l2g(uint8_t *g, const uint8_t *lds, uint32_t n) { memcpy(g, lds, n); }
 };
 
