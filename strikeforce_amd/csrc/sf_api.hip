@@ -233,24 +233,46 @@ static __device__ __forceinline__ void observe_agent(const Params &p, float *out
   const bool zstage = p.Z <= OBS_Z_STAGE;  // a larger zombie table is read where it lies (flat loads through ObsView)
   const int nh = HW_WORDS * p.H, nz = zstage ? ZW_WORDS * p.Z : 0, nb = BW_WORDS * p.B;
   uint32_t *tab_lds = ent + nh + nz + nb;
-  for (int i = tid; i < nh; i += OBS_THREADS) ent[i] = gptr(p.hum)[((size_t)(i / p.H) * p.A + a) * p.H + i % p.H];
-  for (int i = tid; i < nz; i += OBS_THREADS) ent[nh + i] = gptr(p.zom)[((size_t)(i / p.Z) * p.A + a) * p.Z + i % p.Z];
-  for (int i = tid; i < nb; i += OBS_THREADS)
-    ent[nh + nz + i] = gptr(p.bul)[((size_t)(i / p.B) * p.A + a) * p.B + i % p.B];
+  // Every global load of the prologue is issued before the first LDS store waits for one: the first 256 words of each
+  // table and the window's four flag bytes per thread go to registers first.  (Loop by loop, each with its store behind
+  // the load, this was a dozen round trips in a row — most of what a workgroup does before it starts to write.)
+  auto hum_w = [&](int i) { return gptr(p.hum)[((size_t)(i / p.H) * p.A + a) * p.H + i % p.H]; };
+  auto zom_w = [&](int i) { return gptr(p.zom)[((size_t)(i / p.Z) * p.A + a) * p.Z + i % p.Z]; };
+  auto bul_w = [&](int i) { return gptr(p.bul)[((size_t)(i / p.B) * p.A + a) * p.B + i % p.B]; };
+  auto tab_w = [&](int i) { return reinterpret_cast<const SF_GLOBAL uint32_t *>(gptr(p.tab))[i]; };
+  const uint32_t rh = tid < nh ? hum_w(tid) : 0u, rz = tid < nz ? zom_w(tid) : 0u, rb = tid < nb ? bul_w(tid) : 0u;
+  const uint32_t rt = tid < TAB_WORDS ? tab_w(tid) : 0u;
+  const float r_in = tid < 16 ? gptr(p.tab)->obs_in[tid] : 0.f, r_out = tid < 16 ? gptr(p.tab)->obs_out[tid] : 0.f;
+  const int t_n = gptr(p.tab)->obs_n;
   const int pteam = (int)((hf >> HF_TEAM_SH) & 255u);
   const int r0 = pos_r(center) - SF_OBS_WINDOW / 2, c0 = pos_c(center) - SF_OBS_WINDOW / 2, f0 = pos_f(center);
-  if (tid == 0) list_n = 0u, rec_n = (uint32_t)OBS_CLASS_RECS, spill_n = 0u;
-  if (tid < 16) t_in[tid] = gptr(p.tab)->obs_in[tid], t_out[tid] = gptr(p.tab)->obs_out[tid];
-  const int t_n = gptr(p.tab)->obs_n;
-  for (int i = tid; i < TAB_WORDS; i += OBS_THREADS) tab_lds[i] = reinterpret_cast<const SF_GLOBAL uint32_t *>(gptr(p.tab))[i];
-  for (int w = tid; w < OBS_W2; w += OBS_THREADS) {
+  constexpr int CELL_IT = (OBS_W2 + OBS_THREADS - 1) / OBS_THREADS;  // 4
+  uint32_t rfl[CELL_IT];
+#pragma unroll
+  for (int q = 0; q < CELL_IT; ++q) {
+    const int w = tid + q * OBS_THREADS;
     const int i = r0 + w / SF_OBS_WINDOW, j = c0 + w % SF_OBS_WINDOW;
-    uint32_t fl = 0;
+    rfl[q] = (w < OBS_W2 && i >= 0 && j >= 0 && i < p.N && j < p.M) ? (uint32_t)gptr(p.flags)[(size_t)a * p.cells_pad + (size_t)(f0 * p.N + i) * p.M + j] : 0u;
+  }
+  if (tid < nh) ent[tid] = rh;
+  if (tid < nz) ent[nh + tid] = rz;
+  if (tid < nb) ent[nh + nz + tid] = rb;
+  if (tid < TAB_WORDS) tab_lds[tid] = rt;
+  if (tid < 16) t_in[tid] = r_in, t_out[tid] = r_out;
+  if (tid == 0) list_n = 0u, rec_n = (uint32_t)OBS_CLASS_RECS, spill_n = 0u;
+  for (int i = tid + OBS_THREADS; i < nh; i += OBS_THREADS) ent[i] = hum_w(i);  // (tables of more than 256 words)
+  for (int i = tid + OBS_THREADS; i < nz; i += OBS_THREADS) ent[nh + i] = zom_w(i);
+  for (int i = tid + OBS_THREADS; i < nb; i += OBS_THREADS) ent[nh + nz + i] = bul_w(i);
+  for (int i = tid + OBS_THREADS; i < TAB_WORDS; i += OBS_THREADS) tab_lds[i] = tab_w(i);
+#pragma unroll
+  for (int q = 0; q < CELL_IT; ++q) {
+    const int w = tid + q * OBS_THREADS;
+    if (w >= OBS_W2) continue;
+    const uint32_t fl = rfl[q];
     int32_t cdmg = 0;
-    if (i >= 0 && j >= 0 && i < p.N && j < p.M) {
-      const size_t ci = (size_t)(f0 * p.N + i) * p.M + j;
-      fl = gptr(p.flags)[(size_t)a * p.cells_pad + ci];
-      if (fl & SF_CELL_TEMP) cdmg = gptr(p.aux_dmg)[(size_t)a * p.cells + ci];
+    if (fl & SF_CELL_TEMP) {  // (a player-built object: on the map by construction)
+      const int i = r0 + w / SF_OBS_WINDOW, j = c0 + w % SF_OBS_WINDOW;
+      cdmg = gptr(p.aux_dmg)[(size_t)a * p.cells + (size_t)(f0 * p.N + i) * p.M + j];
     }
     occ[w] = 0u, wfl[w] = (uint8_t)fl, wdmg[w] = cdmg, slot[w] = (uint8_t)OBS_NOREC, nzmap[w] = 0u;
   }
