@@ -709,8 +709,9 @@ def main():
                         "the convolution stack — four bias-free convolutions with nothing between them — as one composed matrix on "
                         "those non-zeros, everything behind it in one kernel on the f32 MFMA) -> sample -> K=1 step -> memory reset "
                         "of restarted games, all on device, %d steps; sf_policy_predict_sparse: reset + forward + sample in the "
-                        "forward's two launches, five launches per step (separate_calls: the same loop through "
-                        "sf_policy_forward_sparse_or_dense / sf_policy_act / sf_done_device / sf_policy_reset_memory, eight); "
+                        "forward's two launches — six launches per step, two of them the fallbacks that are idle when every list fits "
+                        "(separate_calls: the same loop through sf_policy_forward_sparse_or_dense / sf_policy_act / sf_done_device / "
+                        "sf_policy_reset_memory, nine); "
                         "agents evaluated on a blank window: %d (lists that do not fit "
                         "are redone from a dense fallback on the device; %d agents took it in the last step)"
                         % (pol["steps"], pol["sparse_overflows"], pol["dense_fallback_agents_last_step"]),

@@ -307,8 +307,8 @@ def test_the_done_view_is_what_sf_done_device_copies():
 
 
 def test_the_closed_loop_through_predict_equals_the_separate_calls_at_bench_size():
-    """bench.py's `policy` loop both ways on configs[2] at 4096 arenas, 150 steps from the same start: five launches per
-    step (sf_policy_predict_sparse reading sf_done_view_device's flags) against eight (forward, act, step, sf_done_device,
+    """bench.py's `policy` loop both ways on configs[2] at 4096 arenas, 150 steps from the same start: six launches per
+    step (sf_policy_predict_sparse reading sf_done_view_device's flags) against nine (forward, act, step, sf_done_device,
     sf_policy_reset_memory).  The two worlds stay digest-identical — every command, hence every draw, hence every restart
     was the same — and so do the networks' memories; games end and restart on the way."""
     A, STEPS = 4096, 150
