@@ -197,6 +197,7 @@ struct Env {
   uint32_t *d_perm = nullptr;  // k_step's launch order (k_rank): arenas by population, for long launches
   int balance = 1;             // SF_BALANCE=0 switches the ordering off (A/B measurements)
   int rank_k_min = 8;          // launches of fewer steps run in arena order
+  int rank_every = 100;        // steps between two orderings (SF_RANK_EVERY; measured: tools/experiments/README.md)
   int steps_since_rank = 1 << 30;  // the order is renewed every >= 100 steps (populations change by one every 20-25 steps)
   float *d_obs = nullptr;
   uint32_t *d_nzprev = nullptr;      // [A * n_agents][961] which floats of the delta-tracked buffer are non-zero
@@ -242,6 +243,8 @@ struct Env {
       balance = (e && e[0] == '0') ? 0 : 1;
       const char *r = getenv("SF_RANK_K_MIN");  // (A/B measurements: the shortest launch that is ordered)
       if (r) rank_k_min = atoi(r);
+      const char *ev = getenv("SF_RANK_EVERY");
+      if (ev && atoi(ev) > 0) rank_every = atoi(ev);
     }
     // tables: one shared player record (block 0) + npc (block 1), or one record per commanded human (blocks 0..15,
     // the account blobs of a lock-step match, gameplay.hpp:120-151) + npc (block 16)
@@ -395,7 +398,7 @@ struct Env {
     if (balance && k >= rank_k_min && p.A >= 1024 && rt.can_rank()) {
       int rc;
       if (!d_perm && (rc = alloc(d_perm, (size_t)p.A))) return rc;
-      if (steps_since_rank >= 100) {
+      if (steps_since_rank >= rank_every) {
         if ((rc = rt.launch_rank(p, d_perm))) return rc;
         steps_since_rank = 0;
       }
